@@ -1,0 +1,547 @@
+/*
+ * nnbvh_oracle.c — TEST INFRASTRUCTURE ONLY (the parity oracle); see nnbvh_oracle.h.
+ *
+ * Scalar C restatement of the reference hot path, arithmetic operation by
+ * arithmetic operation:
+ *   traversal        /root/reference/src/pbrt/cpu/aggregates.cpp:529-579 (closest), 581-624 (any)
+ *   slab test        /root/reference/src/pbrt/util/vecmath.h:1573-1608
+ *   triangle test    /root/reference/src/pbrt/shapes.cpp:172-273 (called from 320-358)
+ *   patch test       /root/reference/src/pbrt/shapes.h:1279-1347, util/math.h:614-637, 1420-1426
+ *   helpers          util/math.h:569-575 (DifferenceOfProducts), util/float.h:100-102 (FMA),
+ *                    util/float.h:195-197 (gamma), util/vecmath.h:999-1004 (Cross), 964-967 (Dot)
+ *
+ * Build contract: -ffp-contract=off (the reference disables contraction,
+ * CMakeLists.txt:134-137); fmaf() appears exactly where the reference calls FMA().
+ *
+ * Pinning: the leaf tests and the slab test are checked bit-for-bit against the
+ * reference's own compiled functions (oracle/_ref/ref_leaf, built by oracle/Makefile
+ * from the sources under /root/reference) and against tests/golden/ vectors
+ * generated from that binary.  The traversal LOOP itself cannot be compiled from the
+ * reference here (Primitive::Intersect lives in cpu/primitive.cpp, which needs the
+ * un-vendored nanovdb header), so its node-visit counts are "parity unpinned" beyond
+ * this restatement, the brute-force cross-check and the aggregate figures recorded in
+ * SURVEY.md §6 — see DESIGN.md §Oracle.
+ */
+#include "nnbvh_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- util/float.h:43,195-197 -------------------------------------------------------- */
+#define ORC_EPS 0x1p-24f /* MachineEpsilon = numeric_limits<float>::epsilon() * 0.5 */
+static inline float orc_gamma(int n) {
+    float ne = (float)n * ORC_EPS;
+    return ne / (1.0f - ne);
+}
+
+/* ---- util/math.h:569-575 ------------------------------------------------------------ */
+static inline float orc_dop(float a, float b, float c, float d) {
+    float cd = c * d;
+    float diff = fmaf(a, b, -cd);
+    float err = fmaf(-c, d, cd);
+    return diff + err;
+}
+
+static inline float orc_max3(float a, float b, float c) {
+    /* std::max({a,b,c}): left fold with operator< */
+    float m = a;
+    if (m < b) m = b;
+    if (m < c) m = c;
+    return m;
+}
+
+/* util/vecmath.h:999-1004 */
+static inline void orc_cross(const float v[3], const float w[3], float out[3]) {
+    out[0] = orc_dop(v[1], w[2], v[2], w[1]);
+    out[1] = orc_dop(v[2], w[0], v[0], w[2]);
+    out[2] = orc_dop(v[0], w[1], v[1], w[0]);
+}
+static inline float orc_dot(const float v[3], const float w[3]) {
+    return v[0] * w[0] + v[1] * w[1] + v[2] * w[2];
+}
+static inline float orc_len2(const float v[3]) {
+    return v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+}
+
+/* ---- slab test: util/vecmath.h:1573-1608 -------------------------------------------- */
+static inline int slab_test(const float *pmin, const float *pmax, const float o[3],
+                            float ray_tmax, const float inv[3], const int neg[3]) {
+    const float *b[2] = {pmin, pmax};
+    const float widen = 1.0f + 2.0f * orc_gamma(3);
+    float tmin = (b[neg[0]][0] - o[0]) * inv[0];
+    float tmax = (b[1 - neg[0]][0] - o[0]) * inv[0];
+    float tymin = (b[neg[1]][1] - o[1]) * inv[1];
+    float tymax = (b[1 - neg[1]][1] - o[1]) * inv[1];
+    tmax *= widen;
+    tymax *= widen;
+    if (tmin > tymax || tymin > tmax) return 0;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (b[neg[2]][2] - o[2]) * inv[2];
+    float tzmax = (b[1 - neg[2]][2] - o[2]) * inv[2];
+    tzmax *= widen;
+    if (tmin > tzmax || tzmin > tmax) return 0;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    return (tmin < ray_tmax) && (tmax > 0.0f);
+}
+
+int orc_slab(const float bounds[6], const float o[3], const float d[3], float ray_tmax) {
+    /* invDir / dirIsNeg as the traversal prepares them, aggregates.cpp:534-535 */
+    float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    int neg[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
+    return slab_test(bounds, bounds + 3, o, ray_tmax, inv, neg);
+}
+
+/* ---- triangle: shapes.cpp:172-273 --------------------------------------------------- */
+int orc_triangle(const float o[3], const float d[3], float tmax, const float p0[3],
+                 const float p1[3], const float p2[3], float out[4]) {
+    /* degenerate-triangle rejection, :176-177 */
+    float e02[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    float e01[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    float cr[3];
+    orc_cross(e02, e01, cr);
+    if (orc_len2(cr) == 0.0f) return 0;
+
+    /* translate to ray origin, :181-183 */
+    float a[3] = {p0[0] - o[0], p0[1] - o[1], p0[2] - o[2]};
+    float b[3] = {p1[0] - o[0], p1[1] - o[1], p1[2] - o[2]};
+    float c[3] = {p2[0] - o[0], p2[1] - o[1], p2[2] - o[2]};
+
+    /* permutation, :186-196; MaxComponentIndex vecmath.h:453-455 */
+    float ax = fabsf(d[0]), ay = fabsf(d[1]), az = fabsf(d[2]);
+    int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+    int kx = kz + 1;
+    if (kx == 3) kx = 0;
+    int ky = kx + 1;
+    if (ky == 3) ky = 0;
+    float dx = d[kx], dy = d[ky], dz = d[kz];
+    float p0x = a[kx], p0y = a[ky], p0z = a[kz];
+    float p1x = b[kx], p1y = b[ky], p1z = b[kz];
+    float p2x = c[kx], p2y = c[ky], p2z = c[kz];
+
+    /* shear, :199-207 (plain mul + add, no FMA) */
+    float sx = -dx / dz, sy = -dy / dz, sz = 1.0f / dz;
+    p0x += sx * p0z;
+    p0y += sy * p0z;
+    p1x += sx * p1z;
+    p1y += sy * p1z;
+    p2x += sx * p2z;
+    p2y += sy * p2z;
+
+    /* edge functions, :210-212 */
+    float e0 = orc_dop(p1x, p2y, p1y, p2x);
+    float e1 = orc_dop(p2x, p0y, p2y, p0x);
+    float e2 = orc_dop(p0x, p1y, p0y, p1x);
+
+    /* double-precision fallback on an exact zero, :215-225 */
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        double p2txp1ty = (double)p2x * (double)p1y;
+        double p2typ1tx = (double)p2y * (double)p1x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0x * (double)p2y;
+        double p0typ2tx = (double)p0y * (double)p2x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1x * (double)p0y;
+        double p1typ0tx = (double)p1y * (double)p0x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+
+    /* sign and determinant tests, :228-232 */
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return 0;
+    float det = e0 + e1 + e2;
+    if (det == 0) return 0;
+
+    /* scaled distance vs range, :235-242 */
+    p0z *= sz;
+    p1z *= sz;
+    p2z *= sz;
+    float tscaled = e0 * p0z + e1 * p1z + e2 * p2z;
+    if (det < 0 && (tscaled >= 0 || tscaled < tmax * det)) return 0;
+    else if (det > 0 && (tscaled <= 0 || tscaled > tmax * det)) return 0;
+
+    /* barycentrics and t, :245-247 */
+    float invdet = 1.0f / det;
+    float b0 = e0 * invdet, b1 = e1 * invdet, b2 = e2 * invdet;
+    float t = tscaled * invdet;
+
+    /* conservative t > 0 bound, :251-269 */
+    float maxzt = orc_max3(fabsf(p0z), fabsf(p1z), fabsf(p2z));
+    float deltaz = orc_gamma(3) * maxzt;
+    float maxxt = orc_max3(fabsf(p0x), fabsf(p1x), fabsf(p2x));
+    float maxyt = orc_max3(fabsf(p0y), fabsf(p1y), fabsf(p2y));
+    float deltax = orc_gamma(5) * (maxxt + maxzt);
+    float deltay = orc_gamma(5) * (maxyt + maxzt);
+    float deltae = 2.0f * (orc_gamma(2) * maxxt * maxyt + deltay * maxxt + deltax * maxyt);
+    float maxe = orc_max3(fabsf(e0), fabsf(e1), fabsf(e2));
+    float deltat =
+        3.0f * (orc_gamma(3) * maxe * maxzt + deltae * maxzt + deltaz * maxe) * fabsf(invdet);
+    if (t <= deltat) return 0;
+
+    out[0] = b0;
+    out[1] = b1;
+    out[2] = b2;
+    out[3] = t;
+    return 1;
+}
+
+/* ---- Quadratic: util/math.h:614-637 ------------------------------------------------- */
+static int orc_quadratic(float a, float b, float c, float *t0, float *t1) {
+    if (a == 0) {
+        if (b == 0) return 0;
+        *t0 = *t1 = -c / b;
+        return 1;
+    }
+    float discrim = orc_dop(b, b, 4.0f * a, c);
+    if (discrim < 0) return 0;
+    float root = sqrtf(discrim);
+    float q = -0.5f * (b + copysignf(root, b));
+    *t0 = q / a;
+    *t1 = c / q;
+    if (*t0 > *t1) {
+        float s = *t0;
+        *t0 = *t1;
+        *t1 = s;
+    }
+    return 1;
+}
+
+/* Determinant(SquareMatrix<3>): util/math.h:1420-1426; m row-major */
+static inline float orc_det3(const float m[9]) {
+    float minor12 = orc_dop(m[4], m[8], m[5], m[7]);
+    float minor02 = orc_dop(m[3], m[8], m[5], m[6]);
+    float minor01 = orc_dop(m[3], m[7], m[4], m[6]);
+    return fmaf(m[2], minor01, orc_dop(m[0], minor12, m[1], minor02));
+}
+
+static inline float orc_maxabs3(const float v[3]) {
+    return orc_max3(fabsf(v[0]), fabsf(v[1]), fabsf(v[2]));
+}
+
+/* Lerp(t, a, b) = (1 - t) * a + t * b, util/vecmath.h:410-412 */
+static inline void orc_lerp3(float t, const float a[3], const float b[3], float out[3]) {
+    float omt = 1.0f - t;
+    for (int k = 0; k < 3; ++k) out[k] = omt * a[k] + t * b[k];
+}
+
+/* one root's (v numerator, t numerator, p2): shapes.h:1303-1316 */
+static inline void blp_root(float u, const float o[3], const float d[3], const float p00[3],
+                            const float p10[3], const float p01[3], const float p11[3],
+                            float *vnum, float *tnum, float *p2) {
+    float uo[3], l1[3], ud[3], deltao[3], perp[3];
+    orc_lerp3(u, p00, p10, uo);
+    orc_lerp3(u, p01, p11, l1);
+    for (int k = 0; k < 3; ++k) ud[k] = l1[k] - uo[k];
+    for (int k = 0; k < 3; ++k) deltao[k] = uo[k] - o[k];
+    orc_cross(d, ud, perp);
+    *p2 = orc_len2(perp);
+    float mv[9] = {deltao[0], d[0], perp[0], deltao[1], d[1], perp[1], deltao[2], d[2], perp[2]};
+    float mt[9] = {deltao[0], ud[0], perp[0], deltao[1], ud[1], perp[1],
+                   deltao[2], ud[2], perp[2]};
+    *vnum = orc_det3(mv);
+    *tnum = orc_det3(mt);
+}
+
+/* ---- bilinear patch: shapes.h:1279-1347 --------------------------------------------- */
+int orc_bilinear_patch(const float o[3], const float d[3], float tmax, const float p00[3],
+                       const float p10[3], const float p01[3], const float p11[3],
+                       float out[3]) {
+    float e10[3], e0111[3], e0100[3], e1110[3], po0[3], po1[3], cr[3];
+    for (int k = 0; k < 3; ++k) {
+        e10[k] = p10[k] - p00[k];
+        e0111[k] = p01[k] - p11[k];
+        e0100[k] = p01[k] - p00[k];
+        e1110[k] = p11[k] - p10[k];
+        po0[k] = p00[k] - o[k];
+        po1[k] = p10[k] - o[k];
+    }
+    orc_cross(e10, e0111, cr);
+    float a = orc_dot(cr, d);
+    orc_cross(po0, d, cr);
+    float c = orc_dot(cr, e0100);
+    orc_cross(po1, d, cr);
+    float b = orc_dot(cr, e1110) - (a + c);
+
+    float u1, u2;
+    if (!orc_quadratic(a, b, c, &u1, &u2)) return 0;
+
+    float eps = orc_gamma(10) * (orc_maxabs3(o) + orc_maxabs3(d) + orc_maxabs3(p00) +
+                                 orc_maxabs3(p10) + orc_maxabs3(p01) + orc_maxabs3(p11));
+
+    float t = tmax, u = 0, v = 0;
+    if (0 <= u1 && u1 <= 1) {
+        float v1, t1, p2;
+        blp_root(u1, o, d, p00, p10, p01, p11, &v1, &t1, &p2);
+        if (t1 > p2 * eps && 0 <= v1 && v1 <= p2) {
+            u = u1;
+            v = v1 / p2;
+            t = t1 / p2;
+        }
+    }
+    if (0 <= u2 && u2 <= 1 && u2 != u1) {
+        float v2, t2, p2;
+        blp_root(u2, o, d, p00, p10, p01, p11, &v2, &t2, &p2);
+        t2 /= p2;
+        if (0 <= v2 && v2 <= p2 && t > t2 && t2 > eps) {
+            t = t2;
+            u = u2;
+            v = v2 / p2;
+        }
+    }
+    if (t >= tmax) return 0;
+    out[0] = u;
+    out[1] = v;
+    out[2] = t;
+    return 1;
+}
+
+/* ---- batched single-function forms -------------------------------------------------- */
+void orc_slab_batch(const float *bounds6, const float *o3, const float *d3, const float *tmax,
+                    int n, uint8_t *out) {
+    for (int i = 0; i < n; ++i)
+        out[i] = (uint8_t)orc_slab(bounds6 + 6 * i, o3 + 3 * i, d3 + 3 * i, tmax[i]);
+}
+void orc_triangle_batch(const float *o3, const float *d3, const float *tmax, const float *p9,
+                        int n, uint8_t *hit, float *out4) {
+    for (int i = 0; i < n; ++i) {
+        float r[4] = {0, 0, 0, 0};
+        hit[i] = (uint8_t)orc_triangle(o3 + 3 * i, d3 + 3 * i, tmax[i], p9 + 9 * i,
+                                       p9 + 9 * i + 3, p9 + 9 * i + 6, r);
+        memcpy(out4 + 4 * i, r, sizeof r);
+    }
+}
+void orc_bilinear_patch_batch(const float *o3, const float *d3, const float *tmax,
+                              const float *p12, int n, uint8_t *hit, float *out3) {
+    for (int i = 0; i < n; ++i) {
+        float r[3] = {0, 0, 0};
+        hit[i] = (uint8_t)orc_bilinear_patch(o3 + 3 * i, d3 + 3 * i, tmax[i], p12 + 12 * i,
+                                             p12 + 12 * i + 3, p12 + 12 * i + 6,
+                                             p12 + 12 * i + 9, r);
+        memcpy(out3 + 3 * i, r, sizeof r);
+    }
+}
+
+/* ---- primitive dispatch (cpu/primitive.cpp:24-32 -> shapes.cpp:320-358, 1131-1156) --- */
+static inline int prim_test(const orc_prim *p, const float *verts, const float o[3],
+                            const float d[3], float tmax, float res[4]) {
+    if (p->kind == 0) {
+        return orc_triangle(o, d, tmax, verts + 3 * (size_t)p->v[0], verts + 3 * (size_t)p->v[1],
+                            verts + 3 * (size_t)p->v[2], res);
+    } else {
+        float uvt[3];
+        if (!orc_bilinear_patch(o, d, tmax, verts + 3 * (size_t)p->v[0],
+                                verts + 3 * (size_t)p->v[1], verts + 3 * (size_t)p->v[2],
+                                verts + 3 * (size_t)p->v[3], uvt))
+            return 0;
+        res[0] = uvt[0];
+        res[1] = uvt[1];
+        res[2] = 0.0f;
+        res[3] = uvt[2];
+        return 1;
+    }
+}
+
+/* ---- BVHAggregate::Intersect, aggregates.cpp:529-579 -------------------------------- */
+static void closest_one(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                        const orc_ray *ray, orc_hit *hit) {
+    float tmax = ray->tmax;
+    const float *o = ray->o, *d = ray->d;
+    float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    int neg[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
+    int to_visit = 0, cur = 0, visited = 0, tests = 0;
+    int stack[64];
+    hit->prim = -1;
+    hit->t = tmax;
+    hit->b0 = hit->b1 = hit->b2 = 0.0f;
+    hit->pad = 0;
+    for (;;) {
+        ++visited;
+        const orc_node *nd = &nodes[cur];
+        if (slab_test(nd->pmin, nd->pmax, o, tmax, inv, neg)) {
+            if (nd->nprims > 0) {
+                for (int i = 0; i < nd->nprims; ++i) {
+                    const orc_prim *p = &prims[nd->offset + i];
+                    float r[4];
+                    ++tests;
+                    if (prim_test(p, verts, o, d, tmax, r)) {
+                        hit->prim = p->id;
+                        hit->b0 = r[0];
+                        hit->b1 = r[1];
+                        hit->b2 = r[2];
+                        hit->t = r[3];
+                        tmax = r[3];
+                    }
+                }
+                if (to_visit == 0) break;
+                cur = stack[--to_visit];
+            } else {
+                if (neg[nd->axis]) {
+                    stack[to_visit++] = cur + 1;
+                    cur = nd->offset;
+                } else {
+                    stack[to_visit++] = nd->offset;
+                    cur = cur + 1;
+                }
+            }
+        } else {
+            if (to_visit == 0) break;
+            cur = stack[--to_visit];
+        }
+    }
+    hit->nodes_visited = visited;
+    hit->prim_tests = tests;
+}
+
+/* ---- BVHAggregate::IntersectP, aggregates.cpp:581-624 ------------------------------- */
+static int any_one(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                   const orc_ray *ray, int *visited_out, int *tests_out) {
+    float tmax = ray->tmax;
+    const float *o = ray->o, *d = ray->d;
+    float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    int neg[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
+    int to_visit = 0, cur = 0, visited = 0, tests = 0, found = 0;
+    int stack[64];
+    for (;;) {
+        ++visited;
+        const orc_node *nd = &nodes[cur];
+        if (slab_test(nd->pmin, nd->pmax, o, tmax, inv, neg)) {
+            if (nd->nprims > 0) {
+                for (int i = 0; i < nd->nprims; ++i) {
+                    float r[4];
+                    ++tests;
+                    if (prim_test(&prims[nd->offset + i], verts, o, d, tmax, r)) {
+                        found = 1;
+                        goto done;
+                    }
+                }
+                if (to_visit == 0) break;
+                cur = stack[--to_visit];
+            } else {
+                if (neg[nd->axis]) {
+                    stack[to_visit++] = cur + 1;
+                    cur = nd->offset;
+                } else {
+                    stack[to_visit++] = nd->offset;
+                    cur = cur + 1;
+                }
+            }
+        } else {
+            if (to_visit == 0) break;
+            cur = stack[--to_visit];
+        }
+    }
+done:
+    *visited_out = visited;
+    *tests_out = tests;
+    return found;
+}
+
+/* ---- batch drivers (pthread fan-out mirrors ParallelFor chunking, util/parallel.cpp:291-299) */
+typedef struct {
+    const orc_node *nodes;
+    const orc_prim *prims;
+    const float *verts;
+    const orc_ray *rays;
+    int64_t begin, end;
+    orc_hit *hits;
+    uint8_t *occ;
+    int32_t *visited;
+    int32_t *tests;
+    int any;
+} orc_job;
+
+static void *orc_worker(void *arg) {
+    orc_job *j = (orc_job *)arg;
+    for (int64_t i = j->begin; i < j->end; ++i) {
+        if (j->any) {
+            int v, t;
+            int f = any_one(j->nodes, j->prims, j->verts, &j->rays[i], &v, &t);
+            j->occ[i] = (uint8_t)f;
+            if (j->visited) j->visited[i] = v;
+            if (j->tests) j->tests[i] = t;
+        } else {
+            closest_one(j->nodes, j->prims, j->verts, &j->rays[i], &j->hits[i]);
+        }
+    }
+    return NULL;
+}
+
+static void orc_run(orc_job base, int64_t n, int nthreads) {
+    if (nthreads <= 1 || n < 2 * (int64_t)nthreads) {
+        base.begin = 0;
+        base.end = n;
+        orc_worker(&base);
+        return;
+    }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    orc_job *jobs = (orc_job *)malloc(sizeof(orc_job) * (size_t)nthreads);
+    for (int k = 0; k < nthreads; ++k) {
+        jobs[k] = base;
+        jobs[k].begin = n * k / nthreads;
+        jobs[k].end = n * (k + 1) / nthreads;
+        pthread_create(&th[k], NULL, orc_worker, &jobs[k]);
+    }
+    for (int k = 0; k < nthreads; ++k) pthread_join(th[k], NULL);
+    free(jobs);
+    free(th);
+}
+
+void orc_intersect_closest(const orc_node *nodes, int n_nodes, const orc_prim *prims,
+                           const float *verts, const orc_ray *rays, int64_t n, orc_hit *hits,
+                           int nthreads) {
+    (void)n_nodes;
+    orc_job j;
+    memset(&j, 0, sizeof j);
+    j.nodes = nodes;
+    j.prims = prims;
+    j.verts = verts;
+    j.rays = rays;
+    j.hits = hits;
+    j.any = 0;
+    orc_run(j, n, nthreads);
+}
+
+void orc_intersect_any(const orc_node *nodes, int n_nodes, const orc_prim *prims,
+                       const float *verts, const orc_ray *rays, int64_t n, uint8_t *occluded,
+                       int32_t *nodes_visited, int32_t *prim_tests, int nthreads) {
+    (void)n_nodes;
+    orc_job j;
+    memset(&j, 0, sizeof j);
+    j.nodes = nodes;
+    j.prims = prims;
+    j.verts = verts;
+    j.rays = rays;
+    j.occ = occluded;
+    j.visited = nodes_visited;
+    j.tests = prim_tests;
+    j.any = 1;
+    orc_run(j, n, nthreads);
+}
+
+void orc_brute_closest(const orc_prim *prims, int n_prims, const float *verts,
+                       const orc_ray *rays, int64_t n, orc_hit *hits) {
+    for (int64_t i = 0; i < n; ++i) {
+        const orc_ray *ray = &rays[i];
+        orc_hit *h = &hits[i];
+        float tmax = ray->tmax;
+        h->prim = -1;
+        h->t = tmax;
+        h->b0 = h->b1 = h->b2 = 0.0f;
+        h->nodes_visited = 0;
+        h->pad = 0;
+        for (int k = 0; k < n_prims; ++k) {
+            float r[4];
+            if (prim_test(&prims[k], verts, ray->o, ray->d, tmax, r)) {
+                h->prim = prims[k].id;
+                h->b0 = r[0];
+                h->b1 = r[1];
+                h->b2 = r[2];
+                h->t = r[3];
+                tmax = r[3];
+            }
+        }
+        h->prim_tests = n_prims;
+    }
+}

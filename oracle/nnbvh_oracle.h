@@ -1,0 +1,89 @@
+/*
+ * nnbvh_oracle.h — TEST INFRASTRUCTURE ONLY (the parity oracle).
+ *
+ * Plain-C CPU restatement of the reference's BVH traversal hot path.  Nothing in
+ * the product (nn_bvh_amd/, include/) may include, link or call this; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and only as
+ * the checker / the reported CPU baseline.
+ *
+ * Wire structs are byte-identical to include/nnbvh.h so the same buffers feed
+ * both sides; they are re-declared here so the oracle has no dependency on the
+ * product headers.
+ */
+#ifndef NNBVH_ORACLE_H
+#define NNBVH_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* == LinearBVHNode, /root/reference/src/pbrt/cpu/aggregates.cpp:129-137 (32 B, alignas 32) */
+typedef struct {
+    float pmin[3];
+    float pmax[3];
+    int32_t offset;   /* leaf: primitivesOffset; interior: secondChildOffset */
+    uint16_t nprims;  /* 0 -> interior */
+    uint8_t axis;
+    uint8_t pad;
+} orc_node;
+
+/* One entry of the leaf-ordered `primitives` vector (aggregates.cpp:176): the
+ * Triangle{meshIndex,triIndex} / BilinearPatch{meshIndex,blpIndex} handle
+ * (shapes.h:1188, 1535) flattened to global vertex indices. */
+typedef struct {
+    int32_t kind; /* 0 = triangle (v[0..2]), 1 = bilinear patch (v = p00,p10,p01,p11) */
+    int32_t id;   /* caller's original primitive index, returned on a hit */
+    int32_t v[4];
+} orc_prim;
+
+typedef struct {
+    float o[3];
+    float tmax;
+    float d[3];
+    float time;
+} orc_ray;
+
+typedef struct {
+    int32_t prim; /* -1 = miss */
+    float t;
+    float b0, b1, b2; /* triangle: barycentrics; patch: b0=u, b1=v, b2=0 */
+    int32_t nodes_visited;
+    int32_t prim_tests;
+    int32_t pad;
+} orc_hit;
+
+/* leaf tests and slab test on single inputs (return 1 = hit) */
+int orc_slab(const float bounds[6], const float o[3], const float d[3], float ray_tmax);
+int orc_triangle(const float o[3], const float d[3], float tmax, const float p0[3],
+                 const float p1[3], const float p2[3], float out_b0b1b2t[4]);
+int orc_bilinear_patch(const float o[3], const float d[3], float tmax, const float p00[3],
+                       const float p10[3], const float p01[3], const float p11[3],
+                       float out_uvt[3]);
+
+/* batched forms used to cross-check against oracle/_ref/ref_leaf */
+void orc_slab_batch(const float *bounds6, const float *o3, const float *d3,
+                    const float *tmax, int n, uint8_t *out);
+void orc_triangle_batch(const float *o3, const float *d3, const float *tmax,
+                        const float *p9, int n, uint8_t *hit, float *out4);
+void orc_bilinear_patch_batch(const float *o3, const float *d3, const float *tmax,
+                              const float *p12, int n, uint8_t *hit, float *out3);
+
+/* BVHAggregate::Intersect / IntersectP over a ray batch; nthreads<=1 = serial */
+void orc_intersect_closest(const orc_node *nodes, int n_nodes, const orc_prim *prims,
+                           const float *verts, const orc_ray *rays, int64_t n,
+                           orc_hit *hits, int nthreads);
+void orc_intersect_any(const orc_node *nodes, int n_nodes, const orc_prim *prims,
+                       const float *verts, const orc_ray *rays, int64_t n,
+                       uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests,
+                       int nthreads);
+
+/* brute force closest hit over all prims in index order (no BVH): a second,
+ * tree-independent check of t for the traversal restatement. */
+void orc_brute_closest(const orc_prim *prims, int n_prims, const float *verts,
+                       const orc_ray *rays, int64_t n, orc_hit *hits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,86 @@
+// ref_leaf.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// Thin batch driver around the REFERENCE's own compiled leaf functions.  It contains
+// no restated arithmetic: it includes the reference headers where they lie under
+// /root/reference/src and calls
+//   pbrt::IntersectTriangle          (src/pbrt/shapes.cpp:172-273; object compiled from that file)
+//   pbrt::IntersectBilinearPatch     (src/pbrt/shapes.h:1279-1347, inline)
+//   pbrt::Bounds3f::IntersectP       (src/pbrt/util/vecmath.h:1573-1608, inline; 7-argument
+//                                     traversal overload, with invDir/dirIsNeg prepared as
+//                                     src/pbrt/cpu/aggregates.cpp:534-535 does)
+// Built by oracle/Makefile into oracle/_ref/ref_leaf (git-ignored).  Used to validate
+// oracle/nnbvh_oracle.c and to generate tests/golden/leaf_*.bin
+// (tools/make_leaf_golden.py).  Never shipped, never on the product path.
+//
+// usage: ref_leaf <tri|blp|slab> <in.bin> <out.bin>
+//   in.bin : int32 n, then n records of float32
+//              tri : o[3] d[3] tmax p0[3] p1[3] p2[3]              (16 floats)
+//              blp : o[3] d[3] tmax p00[3] p10[3] p01[3] p11[3]    (19 floats)
+//              slab: o[3] d[3] tmax pmin[3] pmax[3]                (13 floats)
+//   out.bin: n records: tri  -> int32 hit, float b0 b1 b2 t
+//                       blp  -> int32 hit, float u v t
+//                       slab -> int32 hit
+#include <pbrt/pbrt.h>
+#include <pbrt/ray.h>
+#include <pbrt/shapes.h>
+#include <pbrt/util/vecmath.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+using namespace pbrt;
+
+static Point3f P(const float *p) { return Point3f(p[0], p[1], p[2]); }
+
+int main(int argc, char **argv) {
+    if (argc != 4) {
+        std::fprintf(stderr, "usage: ref_leaf <tri|blp|slab> in.bin out.bin\n");
+        return 2;
+    }
+    int mode = !std::strcmp(argv[1], "tri") ? 0 : !std::strcmp(argv[1], "blp") ? 1 : 2;
+    const int stride[3] = {16, 19, 13};
+    FILE *fi = std::fopen(argv[2], "rb");
+    FILE *fo = std::fopen(argv[3], "wb");
+    if (!fi || !fo) return 3;
+    int32_t n = 0;
+    if (std::fread(&n, 4, 1, fi) != 1) return 4;
+    std::vector<float> in((size_t)n * stride[mode]);
+    if (std::fread(in.data(), 4, in.size(), fi) != in.size()) return 4;
+    for (int i = 0; i < n; ++i) {
+        const float *r = &in[(size_t)i * stride[mode]];
+        Ray ray(P(r), Vector3f(r[3], r[4], r[5]));
+        float tMax = r[6];
+        int32_t hit = 0;
+        float out[4] = {0, 0, 0, 0};
+        int nout = 0;
+        if (mode == 0) {
+            auto ti = IntersectTriangle(ray, tMax, P(r + 7), P(r + 10), P(r + 13));
+            nout = 4;
+            if (ti) {
+                hit = 1;
+                out[0] = ti->b0, out[1] = ti->b1, out[2] = ti->b2, out[3] = ti->t;
+            }
+        } else if (mode == 1) {
+            auto bi = IntersectBilinearPatch(ray, tMax, P(r + 7), P(r + 10), P(r + 13), P(r + 16));
+            nout = 3;
+            if (bi) {
+                hit = 1;
+                out[0] = bi->uv[0], out[1] = bi->uv[1], out[2] = bi->t;
+            }
+        } else {
+            Bounds3f b;
+            b.pMin = P(r + 7);
+            b.pMax = P(r + 10);
+            Vector3f invDir(1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z);
+            int dirIsNeg[3] = {int(invDir.x < 0), int(invDir.y < 0), int(invDir.z < 0)};
+            hit = b.IntersectP(ray.o, ray.d, tMax, invDir, dirIsNeg) ? 1 : 0;
+        }
+        std::fwrite(&hit, 4, 1, fo);
+        if (nout) std::fwrite(out, 4, nout, fo);
+    }
+    std::fclose(fi);
+    std::fclose(fo);
+    return 0;
+}
