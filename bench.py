@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py — Mray/s of the HIP BVH traversal path on the crown workload (BASELINE.json).
+
+One "step" = one sample-per-pixel wavefront pass over the crown film through the hot path,
+with all ray batches already resident in HBM:
+    closest-hit  over 1000x1400 primary rays        (BVHAggregate::Intersect)
+    closest-hit  over the diffuse-bounce rays of those hits
+    any-hit      over the shadow rays of those hits  (BVHAggregate::IntersectP, tMax = 1-1e-4)
+value = rays traced by all ranks / wall time of K steps (max over ranks).
+
+Multi-GPU: the BVH is replicated; each rank owns an interleaved set of 16x16
+image tiles (Morton-ordered ray chunks), traces only its tiles' rays — no data-path
+collective inside the timed steps — and the per-tile results are all-gathered once after the
+timed region (reported separately as allgather_ms).  Per-GPU work is fixed as N grows
+(weak scaling): with --gpus N the job traces N films' worth of tiles (sample index = rank).
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--scene crown] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §HBM)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="crown")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=400_000,
+                    help="rays per class timed on the host cores for cpu_baseline")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the traversal path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from nn_bvh_amd import BVHAggregate, build_tree, make_prims, scene, shard
+    from nn_bvh_amd._lib import HIT_DTYPE
+
+    t0 = time.time()
+    verts, tris, source = scene.load_scene(args.scene)
+    prims = make_prims(tris)
+    tree = build_tree(prims, verts)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, device=local_rank)
+    if rank == 0:
+        log(f"[bench] scene: {source}; {len(tris)} tris, {len(tree.nodes)} nodes, depth {tree.depth}; "
+            f"build+upload {time.time() - t0:.1f}s; grid {agg.info['grid_blocks']} blocks, "
+            f"window {agg.info['stack_window']}")
+
+    # ---- ray batches (synthetic, seeded).  The job is `world` samples per pixel of the film;
+    # rank r traces its interleaved 16x16 tiles of every sample, i.e. one film's worth of rays
+    # per GPU whatever N is (weak scaling).
+    cam_name = args.scene if args.scene in scene.CAMERAS else "crown"
+    xres = scene.CAMERAS[cam_name][4]
+    parts = []
+    for s_idx in range(world):
+        rays_s, px, py = scene.camera_rays(cam_name, seed=1, sample=s_idx, return_pixels=True)
+        parts.append(rays_s[shard.shard_indices(px, py, xres, world, rank)])
+    primary = np.concatenate(parts)
+    shard_bytes = world * shard.shard_counts(px, py, xres, world) * 32  # hit bytes per rank
+    n_primary = len(primary)
+
+    def dev(a):
+        return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
+
+    stream = torch.cuda.current_stream().cuda_stream
+    d_primary = dev(primary)
+    d_hits = torch.empty(n_primary * 32, dtype=torch.uint8, device="cuda")
+    agg.intersect_device(d_primary.data_ptr(), d_hits.data_ptr(), n_primary, stream)
+    torch.cuda.synchronize()
+    hits = d_hits.cpu().numpy().view(HIT_DTYPE)
+    bounce = scene.bounce_rays(primary, hits, verts, tris, seed=2 + rank)
+    lo, hi = verts.min(0), verts.max(0)
+    shadow = scene.shadow_rays(primary, hits, verts, tris, lo + (hi - lo) * [0.3, 0.9, 0.3],
+                               lo + (hi - lo) * [0.7, 1.0, 0.7], seed=3 + rank)
+    d_bounce, d_shadow = dev(bounce), dev(shadow)
+    d_bhits = torch.empty(len(bounce) * 32, dtype=torch.uint8, device="cuda")
+    d_occ = torch.empty(len(shadow), dtype=torch.uint8, device="cuda")
+    rays_per_step = n_primary + len(bounce) + len(shadow)
+
+    def step():
+        agg.intersect_device(d_primary.data_ptr(), d_hits.data_ptr(), n_primary, stream)
+        agg.intersect_device(d_bounce.data_ptr(), d_bhits.data_ptr(), len(bounce), stream)
+        agg.intersect_p_device(d_shadow.data_ptr(), d_occ.data_ptr(), len(shadow), stream=stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([rays_per_step], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_rays_per_step = float(tot.item())
+    else:
+        total_rays_per_step = float(rays_per_step)
+
+    # ---- per-kernel timing with events on the launch stream (dominant kernel = closest-hit) ----
+    def time_kernel(fn, reps):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    reps = max(3, min(args.steps, 10))
+    ms_primary = time_kernel(lambda: agg.intersect_device(d_primary.data_ptr(), d_hits.data_ptr(),
+                                                          n_primary, stream), reps)
+    ms_bounce = time_kernel(lambda: agg.intersect_device(d_bounce.data_ptr(), d_bhits.data_ptr(),
+                                                         len(bounce), stream), reps)
+    ms_shadow = time_kernel(lambda: agg.intersect_p_device(d_shadow.data_ptr(), d_occ.data_ptr(),
+                                                           len(shadow), stream=stream), reps)
+    bhits = d_bhits.cpu().numpy().view(HIT_DTYPE)
+    # algorithmic bytes: 32 in + 32*V + 48*T + 32 out per closest-hit ray
+    def alg_bytes(h):
+        return 64.0 * len(h) + 32.0 * h["nodes_visited"].sum(dtype=np.int64) + \
+            48.0 * h["prim_tests"].sum(dtype=np.int64)
+    bytes_closest = alg_bytes(hits) + alg_bytes(bhits)          # both launches of the kernel
+    ms_closest = ms_primary + ms_bounce
+    achieved = bytes_closest / (ms_closest * 1e-3) / 1e9         # GB/s over the kernel's launches
+
+    allgather_ms = None
+    if world > 1:
+        # film-sample hand-off after the pass: one RCCL all-gather of the per-tile hit records
+        shard.all_gather_records(d_hits, shard_bytes)  # warm-up (communicator setup)
+        barrier()
+        t1 = time.perf_counter()
+        gathered = shard.all_gather_records(d_hits, shard_bytes)
+        barrier()
+        allgather_ms = (time.perf_counter() - t1) * 1e3
+        assert sum(g.numel() for g in gathered) == int(shard_bytes.sum())
+
+    result = None
+    if rank == 0:
+        value = total_rays_per_step * args.steps / elapsed / 1e6
+        result = {
+            "metric": "Mray/s (closest-hit + any-hit)",
+            "value": round(value, 2),
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.scene}: 1 spp wavefront pass, primary+bounce closest-hit and "
+                            f"shadow any-hit, {rays_per_step} rays/step/GPU",
+                "geometry": source,
+                "triangles": int(len(tris)),
+                "nodes": int(len(tree.nodes)),
+                "rays_primary": int(n_primary),
+                "rays_bounce": int(len(bounce)),
+                "rays_shadow": int(len(shadow)),
+                "parallelism": f"tile-sharded x{world}, BVH replicated",
+            },
+            "per_class_mrays": {
+                "primary_closest": round(n_primary / ms_primary / 1e3, 2),
+                "bounce_closest": round(len(bounce) / ms_bounce / 1e3, 2),
+                "shadow_any": round(len(shadow) / ms_shadow / 1e3, 2),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "trace_kernel<closest>",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "alg_bytes_per_ray": round(bytes_closest / (len(hits) + len(bhits)), 1),
+                "mean_nodes_visited": round(float(hits["nodes_visited"].mean()), 2),
+                "mean_prim_tests": round(float(hits["prim_tests"].mean()), 2),
+                "avg_launch_ms": round(ms_closest / 2, 4),
+            },
+        }
+        if allgather_ms is not None:
+            result["allgather_ms"] = round(allgather_ms, 3)
+
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample, rank 0, N=1 only ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_binding as ob
+        cores = os.cpu_count() or 1
+        n = min(args.cpu_sample, n_primary, len(bounce), len(shadow))
+        sel = np.random.default_rng(0).choice(min(n_primary, len(bounce), len(shadow)), n,
+                                              replace=False)
+        sel.sort()
+        t1 = time.perf_counter()
+        c1 = ob.closest(tree.nodes, tree.ordered_prims, verts, primary[sel], nthreads=cores)
+        c2 = ob.closest(tree.nodes, tree.ordered_prims, verts, bounce[sel], nthreads=cores)
+        o3, _, _ = ob.any_hit(tree.nodes, tree.ordered_prims, verts, shadow[sel], nthreads=cores)
+        cpu_s = time.perf_counter() - t1
+        # the checker also checks: the sample must agree with what the GPU produced
+        same = (c1.tobytes() == hits[sel].tobytes() and c2.tobytes() == bhits[sel].tobytes()
+                and (o3 == d_occ.cpu().numpy()[sel]).all())
+        result["cpu_baseline"] = {
+            "value": round(3 * n / cpu_s / 1e6, 3),
+            "unit": "Mray/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"{n} rays of each class (primary, bounce, shadow) of the same batches, "
+                      f"oracle/nnbvh_oracle.c on {cores} threads, {cpu_s:.1f}s",
+            "matches_gpu": bool(same),
+        }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    agg.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

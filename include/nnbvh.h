@@ -1,0 +1,130 @@
+/*
+ * nnbvh.h — C ABI of the MI355X-native BVH traversal path (libnnbvh_hip.so).
+ *
+ * Drop-in boundary for pbrt's BVH hot path.  Each entry point names the reference
+ * interface it replaces (paths relative to /root/reference/src/pbrt):
+ *
+ *   nnbvh_scene_create      <- CreateAccelerator("bvh", prims, ...) / new BVHAggregate(prims)
+ *                              (cpu/aggregates.cpp:1163-1178, 140-190): takes the flattened
+ *                              LinearBVHNode[] (cpu/aggregates.cpp:129-137), the leaf-ordered
+ *                              primitive table (aggregates.cpp:176) and the mesh vertices
+ *                              (util/mesh.h:24-72, already in render space, util/mesh.cpp:36-39)
+ *   nnbvh_scene_bounds      <- BVHAggregate::Bounds()          (cpu/aggregates.cpp:524-527)
+ *   nnbvh_intersect_closest <- BVHAggregate::Intersect()       (cpu/aggregates.cpp:529-579), batched
+ *                              like CPUAggregate::IntersectClosest (wavefront/aggregate.cpp:34-58)
+ *   nnbvh_intersect_any     <- BVHAggregate::IntersectP()      (cpu/aggregates.cpp:581-624), batched
+ *                              like CPUAggregate::IntersectShadow  (wavefront/aggregate.cpp:60-68)
+ *   nnbvh_build_*           <- BVHAggregate ctor + buildRecursive + flattenBVH
+ *                              (cpu/aggregates.cpp:140-387, 505-522); host-side, no GPU needed
+ *
+ * Conventions: plain C, caller-owned buffers, no C++/torch types.  Every function that
+ * can fail returns an int status (0 = NNBVH_OK) or NULL and records a message readable
+ * with nnbvh_last_error() (thread-local); nothing here aborts the host process (the
+ * reference's CHECK/LOG_FATAL would, util/check.h:36-57).  All entry points are
+ * thread-safe; results of a call depend only on that call's inputs.  There is NO CPU
+ * fallback: without a usable HIP device the intersect calls fail with NNBVH_ERR_DEVICE.
+ */
+#ifndef NNBVH_H
+#define NNBVH_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNBVH_OK 0
+#define NNBVH_ERR_ARG 1     /* bad pointer / size / malformed tree */
+#define NNBVH_ERR_DEVICE 2  /* no HIP device, allocation or launch failure */
+#define NNBVH_ERR_DEPTH 3   /* tree deeper than the supported traversal stack */
+
+/* == LinearBVHNode (cpu/aggregates.cpp:129-137): 32 B, 32-B aligned in the reference */
+typedef struct nnbvh_linear_node {
+    float pmin[3];
+    float pmax[3];
+    int32_t offset;   /* leaf: primitivesOffset; interior: secondChildOffset */
+    uint16_t nprims;  /* 0 -> interior node */
+    uint8_t axis;     /* interior: split axis 0/1/2 */
+    uint8_t pad;
+} nnbvh_linear_node;
+
+#define NNBVH_PRIM_TRIANGLE 0       /* Triangle      (shapes.h:833-1192) */
+#define NNBVH_PRIM_BILINEAR_PATCH 1 /* BilinearPatch (shapes.h:1351-1539): v = p00,p10,p01,p11 */
+
+/* One entry of BVHAggregate::primitives: the shape handle flattened to global vertex
+ * indices (Triangle{meshIndex,triIndex} -> mesh->vertexIndices[3*tri..], shapes.cpp:326-328). */
+typedef struct nnbvh_prim {
+    int32_t kind;
+    int32_t id;   /* caller's primitive id, returned in nnbvh_hit.prim */
+    int32_t v[4]; /* indices into the vertex array; v[3] unused for triangles */
+} nnbvh_prim;
+
+/* Ray + tMax (ray.h:18-39 Ray{o,d,time,medium} and the tMax argument), 32 B.
+ * d need NOT be normalised (shadow rays are not, cpu/integrators.h:52-54). */
+typedef struct nnbvh_ray {
+    float o[3];
+    float tmax;
+    float d[3];
+    float time;
+} nnbvh_ray;
+
+/* What TriangleIntersection / BilinearIntersection carry (shapes.h:820-824, 1271-1275)
+ * plus the reference's observables bvhNodesVisited (aggregates.cpp:27) and nTriTests
+ * (shapes.cpp:148), per ray.  32 B. */
+typedef struct nnbvh_hit {
+    int32_t prim; /* -1 = miss */
+    float t;      /* tHit; on a miss: the ray's tmax */
+    float b0, b1, b2; /* triangle barycentrics; patch: b0 = u, b1 = v, b2 = 0 */
+    int32_t nodes_visited;
+    int32_t prim_tests;
+    int32_t pad;
+} nnbvh_hit;
+
+typedef struct nnbvh_scene nnbvh_scene;
+typedef struct nnbvh_build nnbvh_build;
+
+const char *nnbvh_last_error(void);
+int nnbvh_device_count(void);
+
+/* ---- host-side tree construction (no GPU) ---------------------------------------- */
+#define NNBVH_SPLIT_SAH 0
+#define NNBVH_SPLIT_HLBVH 1 /* not implemented in this round: returns NULL */
+#define NNBVH_SPLIT_MIDDLE 2
+#define NNBVH_SPLIT_EQUAL_COUNTS 3
+nnbvh_build *nnbvh_build_create(const nnbvh_prim *prims, int n_prims, const float *verts,
+                                int n_verts, int max_prims_in_node, int split_method);
+const nnbvh_linear_node *nnbvh_build_nodes(const nnbvh_build *b, int *n_nodes);
+const nnbvh_prim *nnbvh_build_ordered_prims(const nnbvh_build *b, int *n_prims);
+int nnbvh_build_depth(const nnbvh_build *b); /* edges root -> deepest leaf */
+void nnbvh_build_destroy(nnbvh_build *b);
+
+/* ---- device scene ------------------------------------------------------------------ */
+nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
+                                const nnbvh_prim *ordered_prims, int n_prims,
+                                const float *verts, int n_verts, int device);
+void nnbvh_scene_destroy(nnbvh_scene *s);
+int nnbvh_scene_bounds(const nnbvh_scene *s, float out_min_max[6]);
+/* what the baked device layout looks like: [0]=interior records, [1]=prim-stream slots,
+ * [2]=tree depth, [3]=device bytes, [4]=persistent grid blocks, [5]=LDS stack window */
+int nnbvh_scene_info(const nnbvh_scene *s, int64_t out[6]);
+
+/* ---- traversal, host buffers (synchronous; copies in and out) ---------------------- */
+int nnbvh_intersect_closest(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits);
+/* nodes_visited / prim_tests may be NULL (then the faster non-counting kernel runs) */
+int nnbvh_intersect_any(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, uint8_t *occluded,
+                        int32_t *nodes_visited, int32_t *prim_tests);
+
+/* ---- traversal, device buffers (asynchronous on `stream`, a hipStream_t; NULL = the
+ *      default stream).  Pointers are device pointers on the scene's device. ----------- */
+int nnbvh_intersect_closest_device(nnbvh_scene *s, const void *d_rays, int64_t n, void *d_hits,
+                                   void *stream);
+int nnbvh_intersect_any_device(nnbvh_scene *s, const void *d_rays, int64_t n, void *d_occluded,
+                               void *d_nodes_visited, void *d_prim_tests, void *stream);
+
+/* tuning knobs (speed only, never results): "stack_window" (LDS entries per lane: 4,8,16,32),
+ * "blocks_per_cu", "xcd_queues" (0/1).  Returns NNBVH_ERR_ARG for unknown keys. */
+int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

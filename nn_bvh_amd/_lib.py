@@ -1,0 +1,91 @@
+"""ctypes binding of libnnbvh_hip.so (include/nnbvh.h).  Loading fails loudly: there is no
+Python or CPU fallback for the traversal path."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnnbvh_hip.so")
+
+# numpy views of the wire structs (byte-identical to include/nnbvh.h)
+NODE_DTYPE = np.dtype([("pmin", "<f4", 3), ("pmax", "<f4", 3), ("offset", "<i4"),
+                       ("nprims", "<u2"), ("axis", "u1"), ("pad", "u1")])
+PRIM_DTYPE = np.dtype([("kind", "<i4"), ("id", "<i4"), ("v", "<i4", 4)])
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("tmax", "<f4"), ("d", "<f4", 3), ("time", "<f4")])
+HIT_DTYPE = np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"),
+                      ("nodes_visited", "<i4"), ("prim_tests", "<i4"), ("pad", "<i4")])
+assert NODE_DTYPE.itemsize == 32 and PRIM_DTYPE.itemsize == 24
+assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 32
+
+EXPORTS = [
+    "nnbvh_last_error", "nnbvh_device_count", "nnbvh_build_create", "nnbvh_build_nodes",
+    "nnbvh_build_ordered_prims", "nnbvh_build_depth", "nnbvh_build_destroy",
+    "nnbvh_scene_create", "nnbvh_scene_destroy", "nnbvh_scene_bounds", "nnbvh_scene_info",
+    "nnbvh_intersect_closest", "nnbvh_intersect_any", "nnbvh_intersect_closest_device",
+    "nnbvh_intersect_any_device", "nnbvh_scene_set_option",
+]
+
+_lib = None
+
+
+class NNBVHError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library (built by nn_bvh_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NNBVHError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the traversal path has no fallback)")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    L.nnbvh_last_error.restype = ctypes.c_char_p
+    L.nnbvh_device_count.restype = i32
+    L.nnbvh_build_create.restype = vp
+    L.nnbvh_build_create.argtypes = [vp, i32, vp, i32, i32, i32]
+    L.nnbvh_build_nodes.restype = vp
+    L.nnbvh_build_nodes.argtypes = [vp, ctypes.POINTER(i32)]
+    L.nnbvh_build_ordered_prims.restype = vp
+    L.nnbvh_build_ordered_prims.argtypes = [vp, ctypes.POINTER(i32)]
+    L.nnbvh_build_depth.restype = i32
+    L.nnbvh_build_depth.argtypes = [vp]
+    L.nnbvh_build_destroy.restype = None
+    L.nnbvh_build_destroy.argtypes = [vp]
+    L.nnbvh_scene_create.restype = vp
+    L.nnbvh_scene_create.argtypes = [vp, i32, vp, i32, vp, i32, i32]
+    L.nnbvh_scene_destroy.restype = None
+    L.nnbvh_scene_destroy.argtypes = [vp]
+    L.nnbvh_scene_bounds.restype = i32
+    L.nnbvh_scene_bounds.argtypes = [vp, vp]
+    L.nnbvh_scene_info.restype = i32
+    L.nnbvh_scene_info.argtypes = [vp, vp]
+    L.nnbvh_intersect_closest.restype = i32
+    L.nnbvh_intersect_closest.argtypes = [vp, vp, i64, vp]
+    L.nnbvh_intersect_any.restype = i32
+    L.nnbvh_intersect_any.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.nnbvh_intersect_closest_device.restype = i32
+    L.nnbvh_intersect_closest_device.argtypes = [vp, vp, i64, vp, vp]
+    L.nnbvh_intersect_any_device.restype = i32
+    L.nnbvh_intersect_any_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.nnbvh_scene_set_option.restype = i32
+    L.nnbvh_scene_set_option.argtypes = [vp, ctypes.c_char_p, i32]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().nnbvh_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NNBVHError(f"{what} failed (status {rc}): {last_error()}")
+
+
+def ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)

@@ -1,0 +1,161 @@
+"""Host-side mirror of the reference's aggregate interface for the accelerated path.
+
+`BVHAggregate` here has the reference's method names and argument meaning
+(/root/reference/src/pbrt/cpu/aggregates.h:27-68: Create / Bounds / Intersect / IntersectP),
+batched the way the wavefront caller batches them (wavefront/aggregate.cpp:34-68).  All
+arithmetic happens in libnnbvh_hip.so on the GPU; numpy/torch only carry buffers.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import HIT_DTYPE, NODE_DTYPE, PRIM_DTYPE, RAY_DTYPE, NNBVHError, check, ptr
+
+SPLIT_METHODS = {"sah": 0, "hlbvh": 1, "middle": 2, "equal": 3}
+
+
+def make_prims(tri_indices=None, patch_indices=None):
+    """Primitive table in creation order: triangles first, then bilinear patches.
+    ids are the running primitive index (the reference's position in `prims`)."""
+    nt = 0 if tri_indices is None else len(tri_indices)
+    npch = 0 if patch_indices is None else len(patch_indices)
+    prims = np.zeros(nt + npch, PRIM_DTYPE)
+    prims["id"] = np.arange(nt + npch, dtype=np.int32)
+    if nt:
+        prims["kind"][:nt] = 0
+        prims["v"][:nt, :3] = np.asarray(tri_indices, np.int32).reshape(nt, 3)
+    if npch:
+        prims["kind"][nt:] = 1
+        prims["v"][nt:] = np.asarray(patch_indices, np.int32).reshape(npch, 4)
+    return prims
+
+
+def make_rays(o, d, tmax=np.inf, time=0.0):
+    o = np.asarray(o, np.float32).reshape(-1, 3)
+    rays = np.zeros(len(o), RAY_DTYPE)
+    rays["o"] = o
+    rays["d"] = np.asarray(d, np.float32).reshape(-1, 3)
+    rays["tmax"] = tmax
+    rays["time"] = time
+    return rays
+
+
+class BuiltTree:
+    """Output of the host builder (BVHAggregate ctor + flattenBVH, aggregates.cpp:140-522)."""
+
+    def __init__(self, nodes, ordered_prims, depth):
+        self.nodes = nodes
+        self.ordered_prims = ordered_prims
+        self.depth = depth
+
+
+def build_tree(prims, verts, max_prims_in_node=4, split_method="sah"):
+    """SAH / middle / equal-counts build on the host (no GPU needed)."""
+    L = _lib.lib()
+    prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+    verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+    if split_method not in SPLIT_METHODS:
+        # aggregates.cpp:735-738 warns and falls back to sah; we report instead
+        raise NNBVHError(f'BVH split method "{split_method}" unknown')
+    h = L.nnbvh_build_create(ptr(prims), len(prims), ptr(verts), len(verts),
+                             int(max_prims_in_node), SPLIT_METHODS[split_method])
+    if not h:
+        raise NNBVHError("nnbvh_build_create: " + _lib.last_error())
+    try:
+        n = ctypes.c_int(0)
+        pn = L.nnbvh_build_nodes(h, ctypes.byref(n))
+        nodes = np.frombuffer((ctypes.c_char * (n.value * 32)).from_address(pn),
+                              NODE_DTYPE).copy()
+        pp = L.nnbvh_build_ordered_prims(h, ctypes.byref(n))
+        ordered = np.frombuffer((ctypes.c_char * (n.value * 24)).from_address(pp),
+                                PRIM_DTYPE).copy()
+        depth = L.nnbvh_build_depth(h)
+    finally:
+        L.nnbvh_build_destroy(h)
+    return BuiltTree(nodes, ordered, depth)
+
+
+class BVHAggregate:
+    """GPU-resident aggregate.  Construct from primitives (builds the tree on the host like
+    BVHAggregate::Create, aggregates.cpp:725-744: splitmethod "sah", maxnodeprims 4) or from
+    an already flattened tree via `from_tree`."""
+
+    def __init__(self, prims, verts, max_prims_in_node=4, split_method="sah", device=0):
+        tree = build_tree(prims, verts, max_prims_in_node, split_method)
+        self._init(tree.nodes, tree.ordered_prims, verts, device, tree.depth)
+
+    @classmethod
+    def from_tree(cls, nodes, ordered_prims, verts, device=0):
+        self = cls.__new__(cls)
+        self._init(nodes, ordered_prims, verts, device, None)
+        return self
+
+    def _init(self, nodes, ordered_prims, verts, device, depth):
+        L = _lib.lib()
+        self.nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
+        self.ordered_prims = np.ascontiguousarray(ordered_prims, PRIM_DTYPE)
+        self.verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        self.device = int(device)
+        self._h = L.nnbvh_scene_create(ptr(self.nodes), len(self.nodes), ptr(self.ordered_prims),
+                                       len(self.ordered_prims), ptr(self.verts), len(self.verts),
+                                       self.device)
+        if not self._h:
+            raise NNBVHError("nnbvh_scene_create: " + _lib.last_error())
+        info = np.zeros(6, np.int64)
+        check(L.nnbvh_scene_info(self._h, ptr(info)), "nnbvh_scene_info")
+        self.info = {"interior_records": int(info[0]), "prim_slots": int(info[1]),
+                     "depth": int(info[2]), "device_bytes": int(info[3]),
+                     "grid_blocks": int(info[4]), "stack_window": int(info[5])}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().nnbvh_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        check(_lib.lib().nnbvh_scene_set_option(self._h, key.encode(), int(value)),
+              f"set_option({key})")
+
+    # -- reference interface ----------------------------------------------------------
+    def Bounds(self):
+        out = np.zeros(6, np.float32)
+        check(_lib.lib().nnbvh_scene_bounds(self._h, ptr(out)), "nnbvh_scene_bounds")
+        return out[:3].copy(), out[3:].copy()
+
+    def Intersect(self, rays):
+        """Closest hit for a host ray batch (RAY_DTYPE) -> HIT_DTYPE array."""
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        check(_lib.lib().nnbvh_intersect_closest(self._h, ptr(rays), len(rays), ptr(hits)),
+              "nnbvh_intersect_closest")
+        return hits
+
+    def IntersectP(self, rays, counts=False):
+        """Any hit -> uint8 occluded[, nodes_visited, prim_tests]."""
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        occ = np.zeros(len(rays), np.uint8)
+        if counts:
+            vis = np.zeros(len(rays), np.int32)
+            tst = np.zeros(len(rays), np.int32)
+            check(_lib.lib().nnbvh_intersect_any(self._h, ptr(rays), len(rays), ptr(occ),
+                                                 ptr(vis), ptr(tst)), "nnbvh_intersect_any")
+            return occ, vis, tst
+        check(_lib.lib().nnbvh_intersect_any(self._h, ptr(rays), len(rays), ptr(occ), None, None),
+              "nnbvh_intersect_any")
+        return occ
+
+    # -- device-resident batches (torch tensors are only buffers + the current stream) ----
+    def intersect_device(self, d_rays, d_hits, n, stream=0):
+        check(_lib.lib().nnbvh_intersect_closest_device(self._h, d_rays, n, d_hits, stream),
+              "nnbvh_intersect_closest_device")
+
+    def intersect_p_device(self, d_rays, d_occ, n, d_visited=None, d_tests=None, stream=0):
+        check(_lib.lib().nnbvh_intersect_any_device(self._h, d_rays, n, d_occ, d_visited, d_tests,
+                                                    stream), "nnbvh_intersect_any_device")

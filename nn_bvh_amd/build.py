@@ -1,0 +1,42 @@
+"""Builds nn_bvh_amd/libnnbvh_hip.so (HIP kernels + C ABI + host BVH builder) for gfx950.
+
+In-tree, explicit hipcc invocation: the .so travels to the GPU box with the repo
+snapshot.  -ffp-contract=off is part of the numerical contract.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libnnbvh_hip.so")
+SOURCES = ["bvh_trace.hip", "bvh_capi.cpp", "bvh_build.cpp"]
+HEADERS = ["bvh_trace.h", "nnbvh_internal.h", os.path.join("..", "..", "include", "nnbvh.h")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile the shared library if it is missing or older than its sources."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libnnbvh_hip.so")
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

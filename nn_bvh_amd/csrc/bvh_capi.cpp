@@ -1,0 +1,534 @@
+// bvh_capi.cpp — the C ABI of include/nnbvh.h: tree validation, baking of the device
+// layout, workspaces and kernel launches.  Host code only (compiled with hipcc for the
+// HIP runtime API).  There is deliberately no CPU traversal in this library: if no HIP
+// device is usable the intersect entry points fail with NNBVH_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bvh_trace.h"
+
+namespace nnbvh {
+
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+
+static bool hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hip_ok(hipSetDevice(dev), "hipSetDevice");
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+struct Workspace {
+    unsigned *queue = nullptr;  // kMaxQueues heads
+    uint2 *spill = nullptr;
+    // grow-only staging for the host-buffer entry points
+    void *d_in = nullptr, *d_out = nullptr, *d_aux0 = nullptr, *d_aux1 = nullptr;
+    size_t in_bytes = 0, out_bytes = 0, aux_bytes = 0;
+};
+
+}  // namespace nnbvh
+
+using namespace nnbvh;
+
+struct nnbvh_scene {
+    int device = 0;
+    int n_cus = 0;
+    int n_interior = 0;
+    int64_t n_slots = 0;
+    int depth = 0;
+    float bounds[6];
+    int root_ref = 0;
+    float4 *d_wide = nullptr;
+    float4 *d_prims = nullptr;
+    size_t device_bytes = 0;
+    // tuning (speed only)
+    int window = 8;
+    int blocks_per_cu = 0;  // 0 = from the occupancy query
+    int xcd_queues = 1;
+    int refill_below = 40;
+    int max_grid_threads = 0;
+    std::mutex mu;
+    std::map<hipStream_t, Workspace> workspaces;
+};
+
+// -------------------------------------------------------------------------------------
+// Tree validation: everything the kernels index with is range-checked here once, so a
+// malformed tree is an NNBVH_ERR_ARG at create time, never a device fault.
+static bool validate_tree(const nnbvh_linear_node *nodes, int n_nodes, int n_prims,
+                          std::vector<uint8_t> &leaf_last, int *depth_out) {
+    if (n_nodes < 1) {
+        set_error("scene_create: tree has no nodes");
+        return false;
+    }
+    std::vector<uint8_t> covered((size_t)n_prims, 0);
+    leaf_last.assign((size_t)n_prims, 0);
+    // iterative DFS; each frame = (node, end bound of its subtree range, depth)
+    struct Frame {
+        int node, end, depth;
+    };
+    std::vector<Frame> st;
+    st.push_back({0, n_nodes, 0});
+    int visited = 0, max_depth = 0;
+    while (!st.empty()) {
+        Frame f = st.back();
+        st.pop_back();
+        ++visited;
+        if (f.node < 0 || f.node >= f.end) {
+            set_error("scene_create: node index outside its subtree range");
+            return false;
+        }
+        max_depth = std::max(max_depth, f.depth);
+        const nnbvh_linear_node &nd = nodes[f.node];
+        if (nd.nprims > 0) {
+            if (f.node + 1 != f.end) {
+                set_error("scene_create: leaf does not close its subtree range (not a DFS layout)");
+                return false;
+            }
+            if (nd.offset < 0 || (int64_t)nd.offset + nd.nprims > n_prims) {
+                set_error("scene_create: leaf primitive range out of bounds");
+                return false;
+            }
+            for (int i = 0; i < nd.nprims; ++i) {
+                if (covered[(size_t)nd.offset + i]) {
+                    set_error("scene_create: primitive referenced by two leaves");
+                    return false;
+                }
+                covered[(size_t)nd.offset + i] = 1;
+            }
+            leaf_last[(size_t)nd.offset + nd.nprims - 1] = 1;
+        } else {
+            if (nd.axis > 2) {
+                set_error("scene_create: interior node axis > 2");
+                return false;
+            }
+            const int c0 = f.node + 1, c1 = nd.offset;
+            if (c1 <= c0 || c1 >= f.end) {
+                set_error("scene_create: secondChildOffset outside the node's subtree range");
+                return false;
+            }
+            st.push_back({c1, f.end, f.depth + 1});
+            st.push_back({c0, c1, f.depth + 1});
+        }
+    }
+    if (visited != n_nodes) {
+        set_error("scene_create: unreachable nodes in the array");
+        return false;
+    }
+    *depth_out = max_depth;
+    return true;
+}
+
+static void put3(float *q, int at, const float *v) {
+    q[at] = v[0];
+    q[at + 1] = v[1];
+    q[at + 2] = v[2];
+}
+
+extern "C" {
+
+const char *nnbvh_last_error(void) { return g_error.c_str(); }
+
+int nnbvh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
+                                const nnbvh_prim *prims, int n_prims, const float *verts,
+                                int n_verts, int device) {
+    if (!nodes || !prims || !verts || n_prims <= 0 || n_verts <= 0) {
+        set_error("scene_create: null or empty input array");
+        return nullptr;
+    }
+    std::vector<uint8_t> leaf_last;
+    int depth = 0;
+    if (!validate_tree(nodes, n_nodes, n_prims, leaf_last, &depth)) return nullptr;
+    if (depth > kMaxStack) {
+        // the reference's nodesToVisit[64] (aggregates.cpp:538) would overflow silently
+        set_error("scene_create: tree deeper than the 64-entry traversal stack");
+        return nullptr;
+    }
+    // prim stream
+    std::vector<int64_t> slot_of((size_t)n_prims + 1, 0);
+    for (int k = 0; k < n_prims; ++k) {
+        const nnbvh_prim &p = prims[k];
+        int nv;
+        if (p.kind == NNBVH_PRIM_TRIANGLE) nv = 3;
+        else if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) nv = 4;
+        else {
+            set_error("scene_create: unknown primitive kind");
+            return nullptr;
+        }
+        for (int j = 0; j < nv; ++j)
+            if (p.v[j] < 0 || p.v[j] >= n_verts) {
+                set_error("scene_create: vertex index out of range");
+                return nullptr;
+            }
+        slot_of[(size_t)k + 1] = slot_of[(size_t)k] + nv;
+    }
+    const int64_t n_slots = slot_of[(size_t)n_prims];
+    if (n_slots >= 0x7fffffffLL) {
+        set_error("scene_create: primitive stream exceeds 2^31 slots");
+        return nullptr;
+    }
+    std::vector<float> stream((size_t)n_slots * 4, 0.0f);
+    for (int k = 0; k < n_prims; ++k) {
+        const nnbvh_prim &p = prims[k];
+        const int nv = p.kind == NNBVH_PRIM_TRIANGLE ? 3 : 4;
+        float *s = &stream[(size_t)slot_of[(size_t)k] * 4];
+        for (int j = 0; j < nv; ++j) put3(s, 4 * j, verts + 3 * (size_t)p.v[j]);
+        uint32_t flags = (leaf_last[(size_t)k] ? kPrimLast : 0u) |
+                         (p.kind == NNBVH_PRIM_BILINEAR_PATCH ? kPrimPatch : 0u);
+        std::memcpy(&s[3], &p.id, 4);
+        std::memcpy(&s[7], &flags, 4);
+    }
+    // interior records
+    std::vector<int> ord((size_t)n_nodes, -1);
+    int n_interior = 0;
+    for (int i = 0; i < n_nodes; ++i)
+        if (nodes[i].nprims == 0) ord[(size_t)i] = n_interior++;
+    auto ref_of = [&](int i) -> int32_t {
+        return nodes[i].nprims == 0 ? ord[(size_t)i]
+                                    : (int32_t) ~(uint32_t)slot_of[(size_t)nodes[i].offset];
+    };
+    std::vector<WideNode> wide((size_t)std::max(n_interior, 1));
+    std::memset(wide.data(), 0, wide.size() * sizeof(WideNode));
+    for (int i = 0; i < n_nodes; ++i) {
+        if (nodes[i].nprims != 0) continue;
+        WideNode &w = wide[(size_t)ord[(size_t)i]];
+        const nnbvh_linear_node &c0 = nodes[i + 1], &c1 = nodes[nodes[i].offset];
+        put3(w.q, 0, c0.pmin);
+        put3(w.q, 3, c0.pmax);
+        put3(w.q, 6, c1.pmin);
+        put3(w.q, 9, c1.pmax);
+        w.ref0 = ref_of(i + 1);
+        w.ref1 = ref_of(nodes[i].offset);
+        w.axis = nodes[i].axis;
+        w.pad = 0;
+    }
+
+    int n_dev = nnbvh_device_count();
+    if (n_dev <= 0 || device < 0 || device >= n_dev) {
+        set_error("scene_create: no usable HIP device (this library has no CPU fallback)");
+        return nullptr;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return nullptr;
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) return nullptr;
+
+    auto *s = new nnbvh_scene;
+    s->device = device;
+    s->n_cus = prop.multiProcessorCount;
+    s->n_interior = n_interior;
+    s->n_slots = n_slots;
+    s->depth = depth;
+    std::memcpy(s->bounds, nodes[0].pmin, 12);
+    std::memcpy(s->bounds + 3, nodes[0].pmax, 12);
+    s->root_ref = ref_of(0);
+    s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
+    const size_t wide_bytes = wide.size() * sizeof(WideNode);
+    const size_t prim_bytes = std::max<size_t>((size_t)n_slots, 1) * 16;
+    bool ok = hip_ok(hipMalloc((void **)&s->d_wide, wide_bytes), "hipMalloc(nodes)") &&
+              hip_ok(hipMalloc((void **)&s->d_prims, prim_bytes), "hipMalloc(prims)") &&
+              hip_ok(hipMemcpy(s->d_wide, wide.data(), wide_bytes, hipMemcpyHostToDevice),
+                     "hipMemcpy(nodes)") &&
+              hip_ok(hipMemcpy(s->d_prims, stream.data(), (size_t)n_slots * 16,
+                               hipMemcpyHostToDevice),
+                     "hipMemcpy(prims)");
+    if (!ok) {
+        if (s->d_wide) (void)hipFree(s->d_wide);
+        if (s->d_prims) (void)hipFree(s->d_prims);
+        delete s;
+        return nullptr;
+    }
+    s->device_bytes = wide_bytes + prim_bytes;
+    if (const char *e = std::getenv("NNBVH_STACK_WINDOW")) nnbvh_scene_set_option(s, "stack_window", atoi(e));
+    if (const char *e = std::getenv("NNBVH_BLOCKS_PER_CU")) nnbvh_scene_set_option(s, "blocks_per_cu", atoi(e));
+    if (const char *e = std::getenv("NNBVH_XCD_QUEUES")) nnbvh_scene_set_option(s, "xcd_queues", atoi(e));
+    if (const char *e = std::getenv("NNBVH_REFILL_BELOW")) nnbvh_scene_set_option(s, "refill_below", atoi(e));
+    return s;
+}
+
+void nnbvh_scene_destroy(nnbvh_scene *s) {
+    if (!s) return;
+    DeviceGuard guard(s->device);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : s->workspaces) {
+        Workspace &w = kv.second;
+        void *ptrs[] = {w.queue, w.spill, w.d_in, w.d_out, w.d_aux0, w.d_aux1};
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    (void)hipFree(s->d_wide);
+    (void)hipFree(s->d_prims);
+    delete s;
+}
+
+int nnbvh_scene_bounds(const nnbvh_scene *s, float out[6]) {
+    if (!s || !out) {
+        set_error("scene_bounds: null argument");
+        return NNBVH_ERR_ARG;
+    }
+    std::memcpy(out, s->bounds, sizeof s->bounds);
+    return NNBVH_OK;
+}
+
+static int grid_blocks(nnbvh_scene *s) {
+    int per_cu = s->blocks_per_cu;
+    if (per_cu <= 0) {
+        // LDS-limited residency: window * 2 KiB per block out of 160 KiB, at most 8 blocks
+        // (32 waves) per CU; the kernel needs no co-residency, so this is speed only.
+        per_cu = std::min(8, 160 / (s->window * 2));
+        per_cu = std::max(per_cu, 1);
+    }
+    per_cu = std::min(per_cu, 8);
+    return s->n_cus * per_cu;
+}
+
+int nnbvh_scene_info(const nnbvh_scene *s, int64_t out[6]) {
+    if (!s || !out) {
+        set_error("scene_info: null argument");
+        return NNBVH_ERR_ARG;
+    }
+    out[0] = s->n_interior;
+    out[1] = s->n_slots;
+    out[2] = s->depth;
+    out[3] = (int64_t)s->device_bytes;
+    out[4] = grid_blocks(const_cast<nnbvh_scene *>(s));
+    out[5] = s->window;
+    return NNBVH_OK;
+}
+
+int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
+    if (!s || !key) {
+        set_error("set_option: null argument");
+        return NNBVH_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lock(s->mu);
+    std::string k(key);
+    if (k == "stack_window") {
+        if (value != 4 && value != 8 && value != 16 && value != 32) {
+            set_error("set_option: stack_window must be 4, 8, 16 or 32");
+            return NNBVH_ERR_ARG;
+        }
+        s->window = value;
+    } else if (k == "blocks_per_cu") {
+        if (value < 0 || value > 8) {
+            set_error("set_option: blocks_per_cu must be 0..8");
+            return NNBVH_ERR_ARG;
+        }
+        s->blocks_per_cu = value;
+    } else if (k == "xcd_queues") {
+        s->xcd_queues = value ? 1 : 0;
+    } else if (k == "refill_below") {
+        if (value < 1 || value > 64) {
+            set_error("set_option: refill_below must be 1..64");
+            return NNBVH_ERR_ARG;
+        }
+        s->refill_below = value;
+    } else {
+        set_error("set_option: unknown key");
+        return NNBVH_ERR_ARG;
+    }
+    return NNBVH_OK;
+}
+
+}  // extern "C"
+
+// One workspace per stream: launches on one stream are ordered, so they may share the
+// queue heads and the spill array; launches on different streams get their own.
+static Workspace *workspace_for(nnbvh_scene *s, hipStream_t stream) {
+    auto it = s->workspaces.find(stream);
+    if (it != s->workspaces.end()) return &it->second;
+    Workspace w;
+    const size_t spill_bytes = (size_t)(s->depth + 1) * (size_t)s->max_grid_threads * sizeof(uint2);
+    if (!hip_ok(hipMalloc((void **)&w.queue, kMaxQueues * kQueueStrideWords * sizeof(unsigned)),
+                "hipMalloc(queue)"))
+        return nullptr;
+    if (!hip_ok(hipMalloc((void **)&w.spill, spill_bytes), "hipMalloc(spill)")) {
+        (void)hipFree(w.queue);
+        return nullptr;
+    }
+    return &(s->workspaces[stream] = w);
+}
+
+static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void *d_hits,
+                  void *d_occ, void *d_vis, void *d_tests, hipStream_t stream, Workspace *w) {
+    TraceParams p;
+    p.wide = s->d_wide;
+    p.prims = s->d_prims;
+    std::memcpy(p.rootMin, s->bounds, 12);
+    std::memcpy(p.rootMax, s->bounds + 3, 12);
+    p.rootRef = s->root_ref;
+    p.rays = (const nnbvh_ray *)d_rays;
+    p.hits = (nnbvh_hit *)d_hits;
+    p.occluded = (uint8_t *)d_occ;
+    p.visitedOut = (int32_t *)d_vis;
+    p.testsOut = (int32_t *)d_tests;
+    p.n = (long)n;
+    p.queue = w->queue;
+    p.nQueues = s->xcd_queues ? kMaxQueues : 1;
+    p.refillBelow = s->refill_below;
+    p.spill = w->spill;
+    if (!hip_ok(hipMemsetAsync(w->queue, 0, kMaxQueues * kQueueStrideWords * sizeof(unsigned),
+                               stream),
+                "hipMemsetAsync(queue)"))
+        return NNBVH_ERR_DEVICE;
+    // never launch more threads than there are rays to start with (tiny batches)
+    int blocks = grid_blocks(s);
+    const int64_t need = (n + kBlockThreads - 1) / kBlockThreads;
+    if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
+    if (!hip_ok(launch_trace(mode, p, s->window, blocks, stream), "trace kernel launch"))
+        return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
+}
+
+static bool grow(void **ptr, size_t *have, size_t need, const char *what) {
+    if (*have >= need) return true;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *have = 0;
+    if (!hip_ok(hipMalloc(ptr, need), what)) return false;
+    *have = need;
+    return true;
+}
+
+extern "C" {
+
+int nnbvh_intersect_closest_device(nnbvh_scene *s, const void *d_rays, int64_t n, void *d_hits,
+                                   void *stream) {
+    if (!s || n < 0 || (n > 0 && (!d_rays || !d_hits))) {
+        set_error("intersect_closest_device: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    if (n == 0) return NNBVH_OK;
+    if (n >= 0x7fffffffLL) {
+        set_error("intersect_closest_device: at most 2^31-1 rays per call");
+        return NNBVH_ERR_ARG;
+    }
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(s->mu);
+    Workspace *w = workspace_for(s, (hipStream_t)stream);
+    if (!w) return NNBVH_ERR_DEVICE;
+    return launch(s, 0, d_rays, n, d_hits, nullptr, nullptr, nullptr, (hipStream_t)stream, w);
+}
+
+int nnbvh_intersect_any_device(nnbvh_scene *s, const void *d_rays, int64_t n, void *d_occluded,
+                               void *d_nodes_visited, void *d_prim_tests, void *stream) {
+    if (!s || n < 0 || (n > 0 && (!d_rays || !d_occluded))) {
+        set_error("intersect_any_device: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    if (n == 0) return NNBVH_OK;
+    if (n >= 0x7fffffffLL) {
+        set_error("intersect_any_device: at most 2^31-1 rays per call");
+        return NNBVH_ERR_ARG;
+    }
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(s->mu);
+    Workspace *w = workspace_for(s, (hipStream_t)stream);
+    if (!w) return NNBVH_ERR_DEVICE;
+    const int mode = (d_nodes_visited || d_prim_tests) ? 1 : 2;
+    return launch(s, mode, d_rays, n, nullptr, d_occluded, d_nodes_visited, d_prim_tests,
+                  (hipStream_t)stream, w);
+}
+
+int nnbvh_intersect_closest(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits) {
+    if (!s || n < 0 || (n > 0 && (!rays || !hits))) {
+        set_error("intersect_closest: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    if (n == 0) return NNBVH_OK;
+    if (n >= 0x7fffffffLL) {
+        set_error("intersect_closest: at most 2^31-1 rays per call");
+        return NNBVH_ERR_ARG;
+    }
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(s->mu);  // host path: one call at a time per scene
+    Workspace *w = workspace_for(s, nullptr);
+    if (!w) return NNBVH_ERR_DEVICE;
+    const size_t bytes = (size_t)n * 32;
+    if (!grow(&w->d_in, &w->in_bytes, bytes, "hipMalloc(rays)") ||
+        !grow(&w->d_out, &w->out_bytes, bytes, "hipMalloc(hits)"))
+        return NNBVH_ERR_DEVICE;
+    if (!hip_ok(hipMemcpyAsync(w->d_in, rays, bytes, hipMemcpyHostToDevice, nullptr), "copy rays"))
+        return NNBVH_ERR_DEVICE;
+    int rc = launch(s, 0, w->d_in, n, w->d_out, nullptr, nullptr, nullptr, nullptr, w);
+    if (rc != NNBVH_OK) return rc;
+    if (!hip_ok(hipMemcpyAsync(hits, w->d_out, bytes, hipMemcpyDeviceToHost, nullptr), "copy hits") ||
+        !hip_ok(hipStreamSynchronize(nullptr), "trace kernel"))
+        return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
+}
+
+int nnbvh_intersect_any(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, uint8_t *occluded,
+                        int32_t *nodes_visited, int32_t *prim_tests) {
+    if (!s || n < 0 || (n > 0 && (!rays || !occluded))) {
+        set_error("intersect_any: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    if (n == 0) return NNBVH_OK;
+    if (n >= 0x7fffffffLL) {
+        set_error("intersect_any: at most 2^31-1 rays per call");
+        return NNBVH_ERR_ARG;
+    }
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(s->mu);
+    Workspace *w = workspace_for(s, nullptr);
+    if (!w) return NNBVH_ERR_DEVICE;
+    const bool counts = nodes_visited || prim_tests;
+    if (!grow(&w->d_in, &w->in_bytes, (size_t)n * 32, "hipMalloc(rays)") ||
+        !grow(&w->d_out, &w->out_bytes, (size_t)n, "hipMalloc(occluded)"))
+        return NNBVH_ERR_DEVICE;
+    if (counts) {
+        // both count arrays live in one allocation of 2 * n int32
+        size_t have = w->aux_bytes;
+        if (!grow(&w->d_aux0, &have, (size_t)n * 8, "hipMalloc(counts)")) return NNBVH_ERR_DEVICE;
+        w->aux_bytes = have;
+    }
+    int32_t *d_vis = counts ? (int32_t *)w->d_aux0 : nullptr;
+    int32_t *d_tst = counts ? d_vis + n : nullptr;
+    if (!hip_ok(hipMemcpyAsync(w->d_in, rays, (size_t)n * 32, hipMemcpyHostToDevice, nullptr),
+                "copy rays"))
+        return NNBVH_ERR_DEVICE;
+    int rc = launch(s, counts ? 1 : 2, w->d_in, n, nullptr, w->d_out, d_vis, d_tst, nullptr, w);
+    if (rc != NNBVH_OK) return rc;
+    bool ok = hip_ok(hipMemcpyAsync(occluded, w->d_out, (size_t)n, hipMemcpyDeviceToHost, nullptr),
+                     "copy occluded");
+    if (ok && nodes_visited)
+        ok = hip_ok(hipMemcpyAsync(nodes_visited, d_vis, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr),
+                    "copy counts");
+    if (ok && prim_tests)
+        ok = hip_ok(hipMemcpyAsync(prim_tests, d_tst, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr),
+                    "copy counts");
+    ok = ok && hip_ok(hipStreamSynchronize(nullptr), "trace kernel");
+    return ok ? NNBVH_OK : NNBVH_ERR_DEVICE;
+}
+
+}  // extern "C"

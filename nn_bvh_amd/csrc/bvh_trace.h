@@ -1,0 +1,35 @@
+// bvh_trace.h — launch interface between the C ABI (bvh_capi.cpp) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nnbvh.h"
+#include "nnbvh_internal.h"
+
+namespace nnbvh {
+
+constexpr int kBlockThreads = 256;   // 4 wavefronts
+constexpr int kMaxQueues = 8;        // one ray queue per XCD
+constexpr int kQueueStrideWords = 32;  // each queue head on its own 128-B line
+
+struct TraceParams {
+    const float4 *wide;   // interior records, 4 x float4 each
+    const float4 *prims;  // prim stream, 16-B slots
+    float rootMin[3], rootMax[3];
+    int rootRef;
+    const nnbvh_ray *rays;
+    nnbvh_hit *hits;        // MODE 0
+    uint8_t *occluded;      // MODE 1/2
+    int32_t *visitedOut;    // MODE 1, nullable
+    int32_t *testsOut;      // MODE 1, nullable
+    long n;
+    unsigned *queue;        // nQueues heads, kQueueStrideWords apart, zeroed before launch
+    int nQueues;
+    int refillBelow;        // refill idle lanes once fewer than this many lanes are active
+    uint2 *spill;           // [kMaxStack][grid threads] overflow of the LDS stack window
+};
+
+hipError_t launch_trace(int mode, const TraceParams &p, int window, int blocks,
+                        hipStream_t stream);
+
+}  // namespace nnbvh

@@ -1,0 +1,508 @@
+// bvh_trace.hip — hand-written gfx950 traversal kernels for the nnbvh C ABI.
+//
+// What is computed (reference: /root/reference/src/pbrt):
+//   closest hit   BVHAggregate::Intersect   cpu/aggregates.cpp:529-579
+//   any hit       BVHAggregate::IntersectP  cpu/aggregates.cpp:581-624
+//   slab test     Bounds3::IntersectP       util/vecmath.h:1573-1608
+//   triangle      IntersectTriangle         shapes.cpp:172-273
+//   patch         IntersectBilinearPatch    shapes.h:1279-1347 (+ util/math.h:614-637, 1420-1426)
+// Results (hit primitive, t, barycentrics, node-visit and primitive-test counts) are
+// bit-identical to that code; HOW it is computed is CDNA4-specific:
+//   * persistent 64-lane wavefronts pull rays from a global queue; lanes whose ray has
+//     terminated are refilled in place (ballot + mbcnt compaction of the idle lanes), so
+//     SIMD slots stay occupied although rays visit 1..400 nodes each;
+//   * one 64-B "both children" record per interior node (nnbvh_internal.h) halves the
+//     length of the dependent-load chain of the reference's 32-B node walk; the far child
+//     is pushed WITH its slab entry distance, so the deferred box test the reference
+//     performs when it pops the node (`tMin < tMax` with the then-current tMax) needs no
+//     memory access at all and still gives the identical boolean;
+//   * the per-lane traversal stack is a short ring window in LDS ([entry][lane], bank-
+//     conflict-free) that spills its oldest entry to a coalesced HBM scratch array only
+//     when a ray's pending-node list outgrows the window;
+//   * fp32 arithmetic is emitted with -ffp-contract=off; __builtin_fmaf appears exactly
+//     where the reference calls FMA(); division and sqrt are IEEE (hipcc default).
+// No MFMA: this is pointer chasing + branchy fp32, bounded by cache/HBM request rate.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bvh_trace.h"
+
+namespace nnbvh {
+
+#define DEV static __device__ __forceinline__
+
+// util/float.h:43,195-197 — evaluated in float exactly as the reference's constexpr
+DEV constexpr float gamma_f(int n) {
+    return ((float)n * 0x1p-24f) / (1.0f - (float)n * 0x1p-24f);
+}
+
+// util/math.h:569-575
+DEV float dop(float a, float b, float c, float d) {
+    float cd = c * d;
+    float diff = __builtin_fmaf(a, b, -cd);
+    float err = __builtin_fmaf(-c, d, cd);
+    return diff + err;
+}
+
+DEV float max3(float a, float b, float c) {  // std::max({a,b,c})
+    float m = a;
+    if (m < b) m = b;
+    if (m < c) m = c;
+    return m;
+}
+
+struct V3 {
+    float x, y, z;
+};
+DEV V3 cross(V3 v, V3 w) {  // util/vecmath.h:999-1004
+    return {dop(v.y, w.z, v.z, w.y), dop(v.z, w.x, v.x, w.z), dop(v.x, w.y, v.y, w.x)};
+}
+DEV float dot(V3 v, V3 w) { return v.x * w.x + v.y * w.y + v.z * w.z; }
+DEV float len2(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+DEV V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV float maxabs(V3 v) { return max3(__builtin_fabsf(v.x), __builtin_fabsf(v.y), __builtin_fabsf(v.z)); }
+DEV float sel3(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+
+struct RayState {
+    V3 o, d, inv;
+    bool negx, negy, negz;
+};
+
+// Slab test of util/vecmath.h:1573-1608 split in two: everything that does not involve
+// the ray's tMax is evaluated here (`early` = all of the reference's early-outs passed and
+// box tMax > 0), and the entry distance is returned so that the remaining conjunct
+// `tMin < raytMax` can be evaluated now (near child) or when the node is popped (far child).
+DEV bool slab_partial(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                      const RayState &r, float &tEntry) {
+    constexpr float widen = 1.0f + 2.0f * gamma_f(3);
+    float tMin = ((r.negx ? mxx : mnx) - r.o.x) * r.inv.x;
+    float tMax = ((r.negx ? mnx : mxx) - r.o.x) * r.inv.x;
+    float tyMin = ((r.negy ? mxy : mny) - r.o.y) * r.inv.y;
+    float tyMax = ((r.negy ? mny : mxy) - r.o.y) * r.inv.y;
+    tMax *= widen;
+    tyMax *= widen;
+    if (tMin > tyMax || tyMin > tMax) return false;
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    float tzMin = ((r.negz ? mxz : mnz) - r.o.z) * r.inv.z;
+    float tzMax = ((r.negz ? mnz : mxz) - r.o.z) * r.inv.z;
+    tzMax *= widen;
+    if (tMin > tzMax || tzMin > tMax) return false;
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    tEntry = tMin;
+    return tMax > 0.0f;
+}
+
+// shapes.cpp:172-273
+DEV bool triangle_test(const RayState &r, float tMax, V3 p0, V3 p1, V3 p2, float &b0, float &b1,
+                       float &b2, float &tHit) {
+    if (len2(cross(sub(p2, p0), sub(p1, p0))) == 0.0f) return false;
+    V3 a = sub(p0, r.o), b = sub(p1, r.o), c = sub(p2, r.o);
+    float ax = __builtin_fabsf(r.d.x), ay = __builtin_fabsf(r.d.y), az = __builtin_fabsf(r.d.z);
+    int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+    int kx = kz + 1;
+    if (kx == 3) kx = 0;
+    int ky = kx + 1;
+    if (ky == 3) ky = 0;
+    float dx = sel3(r.d, kx), dy = sel3(r.d, ky), dz = sel3(r.d, kz);
+    float p0x = sel3(a, kx), p0y = sel3(a, ky), p0z = sel3(a, kz);
+    float p1x = sel3(b, kx), p1y = sel3(b, ky), p1z = sel3(b, kz);
+    float p2x = sel3(c, kx), p2y = sel3(c, ky), p2z = sel3(c, kz);
+    float sx = -dx / dz, sy = -dy / dz, sz = 1.0f / dz;
+    p0x += sx * p0z;
+    p0y += sy * p0z;
+    p1x += sx * p1z;
+    p1y += sy * p1z;
+    p2x += sx * p2z;
+    p2y += sy * p2z;
+    float e0 = dop(p1x, p2y, p1y, p2x);
+    float e1 = dop(p2x, p0y, p2y, p0x);
+    float e2 = dop(p0x, p1y, p0y, p1x);
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {  // :215-225, fp64 on device
+        double p2txp1ty = (double)p2x * (double)p1y;
+        double p2typ1tx = (double)p2y * (double)p1x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0x * (double)p2y;
+        double p0typ2tx = (double)p0y * (double)p2x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1x * (double)p0y;
+        double p1typ0tx = (double)p1y * (double)p0x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0) return false;
+    p0z *= sz;
+    p1z *= sz;
+    p2z *= sz;
+    float tScaled = e0 * p0z + e1 * p1z + e2 * p2z;
+    if (det < 0 && (tScaled >= 0 || tScaled < tMax * det)) return false;
+    else if (det > 0 && (tScaled <= 0 || tScaled > tMax * det)) return false;
+    float invDet = 1.0f / det;
+    float t = tScaled * invDet;
+    float maxZt = max3(__builtin_fabsf(p0z), __builtin_fabsf(p1z), __builtin_fabsf(p2z));
+    float deltaZ = gamma_f(3) * maxZt;
+    float maxXt = max3(__builtin_fabsf(p0x), __builtin_fabsf(p1x), __builtin_fabsf(p2x));
+    float maxYt = max3(__builtin_fabsf(p0y), __builtin_fabsf(p1y), __builtin_fabsf(p2y));
+    float deltaX = gamma_f(5) * (maxXt + maxZt);
+    float deltaY = gamma_f(5) * (maxYt + maxZt);
+    float deltaE = 2.0f * (gamma_f(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    float maxE = max3(__builtin_fabsf(e0), __builtin_fabsf(e1), __builtin_fabsf(e2));
+    float deltaT = 3.0f * (gamma_f(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) *
+                   __builtin_fabsf(invDet);
+    if (t <= deltaT) return false;
+    b0 = e0 * invDet;
+    b1 = e1 * invDet;
+    b2 = e2 * invDet;
+    tHit = t;
+    return true;
+}
+
+// util/math.h:614-637
+DEV bool quadratic(float a, float b, float c, float &t0, float &t1) {
+    if (a == 0) {
+        if (b == 0) return false;
+        t0 = t1 = -c / b;
+        return true;
+    }
+    float discrim = dop(b, b, 4.0f * a, c);
+    if (discrim < 0) return false;
+    float root = __builtin_sqrtf(discrim);
+    float q = -0.5f * (b + __builtin_copysignf(root, b));
+    t0 = q / a;
+    t1 = c / q;
+    if (t0 > t1) {
+        float s = t0;
+        t0 = t1;
+        t1 = s;
+    }
+    return true;
+}
+
+// util/math.h:1420-1426 with rows (r0, r1, r2)
+DEV float det3(V3 r0, V3 r1, V3 r2) {
+    float minor12 = dop(r1.y, r2.z, r1.z, r2.y);
+    float minor02 = dop(r1.x, r2.z, r1.z, r2.x);
+    float minor01 = dop(r1.x, r2.y, r1.y, r2.x);
+    return __builtin_fmaf(r0.z, minor01, dop(r0.x, minor12, r0.y, minor02));
+}
+
+DEV V3 lerp3(float t, V3 a, V3 b) {  // (1 - t) * a + t * b, util/vecmath.h:410-412
+    float omt = 1.0f - t;
+    return {omt * a.x + t * b.x, omt * a.y + t * b.y, omt * a.z + t * b.z};
+}
+
+DEV void patch_root(float u, const RayState &r, V3 p00, V3 p10, V3 p01, V3 p11, float &vnum,
+                    float &tnum, float &p2) {
+    V3 uo = lerp3(u, p00, p10);
+    V3 ud = sub(lerp3(u, p01, p11), uo);
+    V3 deltao = sub(uo, r.o);
+    V3 perp = cross(r.d, ud);
+    p2 = len2(perp);
+    vnum = det3({deltao.x, r.d.x, perp.x}, {deltao.y, r.d.y, perp.y}, {deltao.z, r.d.z, perp.z});
+    tnum = det3({deltao.x, ud.x, perp.x}, {deltao.y, ud.y, perp.y}, {deltao.z, ud.z, perp.z});
+}
+
+// shapes.h:1279-1347
+DEV bool patch_test(const RayState &r, float tMax, V3 p00, V3 p10, V3 p01, V3 p11, float &uOut,
+                    float &vOut, float &tOut) {
+    float a = dot(cross(sub(p10, p00), sub(p01, p11)), r.d);
+    float c = dot(cross(sub(p00, r.o), r.d), sub(p01, p00));
+    float b = dot(cross(sub(p10, r.o), r.d), sub(p11, p10)) - (a + c);
+    float u1, u2;
+    if (!quadratic(a, b, c, u1, u2)) return false;
+    float eps = gamma_f(10) * (maxabs(r.o) + maxabs(r.d) + maxabs(p00) + maxabs(p10) +
+                               maxabs(p01) + maxabs(p11));
+    float t = tMax, u = 0.0f, v = 0.0f;
+    if (0 <= u1 && u1 <= 1) {
+        float v1, t1, p2;
+        patch_root(u1, r, p00, p10, p01, p11, v1, t1, p2);
+        if (t1 > p2 * eps && 0 <= v1 && v1 <= p2) {
+            u = u1;
+            v = v1 / p2;
+            t = t1 / p2;
+        }
+    }
+    if (0 <= u2 && u2 <= 1 && u2 != u1) {
+        float v2, t2, p2;
+        patch_root(u2, r, p00, p10, p01, p11, v2, t2, p2);
+        t2 /= p2;
+        if (0 <= v2 && v2 <= p2 && t > t2 && t2 > eps) {
+            t = t2;
+            u = u2;
+            v = v2 / p2;
+        }
+    }
+    if (t >= tMax) return false;
+    uOut = u;
+    vOut = v;
+    tOut = t;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------
+constexpr int kDone = (int)0x80000000;  // never a leaf ref: ~slot with slot = 0x7fffffff
+
+// MODE 0: closest hit (counts always)
+// MODE 1: any hit with exact node-visit / prim-test counts (pushes every far child)
+// MODE 2: any hit, occlusion flag only
+template <int MODE, int W>
+__global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
+    __shared__ int s_ref[kBlockThreads / 64][W][64];
+    __shared__ float s_key[kBlockThreads / 64][W][64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int gtid = blockIdx.x * kBlockThreads + threadIdx.x;
+    int(*sref)[64] = s_ref[wave];
+    float(*skey)[64] = s_key[wave];
+    uint2 *spill = p.spill + gtid;
+    const long spillStride = (long)gridDim.x * kBlockThreads;
+
+    // which queue this wave drains first: its XCD's share of the batch (speed only)
+    int q = 0;
+    if (p.nQueues > 1) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        q = (int)(xcc & 0xf) % p.nQueues;
+    }
+    int queuesTried = 0;
+
+    RayState r;
+    float tMax = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
+    int hitPrim = -1, visited = 0, tests = 0;
+    int cur = kDone, sp = 0, base = 0;
+    long ri = -1;        // ray this lane carries, -1 = none
+    bool found = false;  // MODE 1/2
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- retire finished rays, refill idle lanes ---------------------------------
+        const bool idle = (cur == kDone);
+        if (idle && ri >= 0) {
+            if (MODE == 0) {
+                float4 h0, h1;
+                h0.x = __int_as_float(hitPrim);
+                h0.y = tMax;
+                h0.z = hb0;
+                h0.w = hb1;
+                h1.x = hb2;
+                h1.y = __int_as_float(visited);
+                h1.z = __int_as_float(tests);
+                h1.w = 0.0f;
+                float4 *out = reinterpret_cast<float4 *>(p.hits) + 2 * ri;
+                out[0] = h0;
+                out[1] = h1;
+            } else {
+                p.occluded[ri] = found ? 1 : 0;
+                if (MODE == 1) {
+                    if (p.visitedOut) p.visitedOut[ri] = visited;
+                    if (p.testsOut) p.testsOut[ri] = tests;
+                }
+            }
+            ri = -1;
+        }
+        const unsigned long long idleMask = __ballot(idle);
+        if (idleMask == ~0ull && exhausted) break;
+        if (!exhausted && idleMask != 0ull) {
+            const int nIdle = __popcll(idleMask);
+            long start = 0;
+            for (;;) {  // find a queue with work left (own XCD's first, then steal)
+                const long qBegin = p.n * q / p.nQueues, qEnd = p.n * (q + 1) / p.nQueues;
+                unsigned got = 0;
+                if (lane == 0) got = atomicAdd(&p.queue[q * kQueueStrideWords], (unsigned)nIdle);
+                got = __builtin_amdgcn_readfirstlane(got);
+                start = qBegin + (long)got;
+                if (start < qEnd) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi(
+                        (unsigned)(idleMask >> 32),
+                        __builtin_amdgcn_mbcnt_lo((unsigned)idleMask, 0u));
+                    if (idle && start + rank < qEnd) ri = start + rank;
+                    break;
+                }
+                if (++queuesTried >= p.nQueues) {
+                    exhausted = true;
+                    break;
+                }
+                q = (q + 1 == p.nQueues) ? 0 : q + 1;
+            }
+            if (ri >= 0 && idle) {
+                const float4 *in = reinterpret_cast<const float4 *>(p.rays) + 2 * ri;
+                const float4 r0 = in[0], r1 = in[1];
+                r.o = {r0.x, r0.y, r0.z};
+                tMax = r0.w;
+                r.d = {r1.x, r1.y, r1.z};
+                // aggregates.cpp:534-535
+                r.inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+                r.negx = r.inv.x < 0;
+                r.negy = r.inv.y < 0;
+                r.negz = r.inv.z < 0;
+                hitPrim = -1;
+                hb0 = hb1 = hb2 = 0.0f;
+                visited = 1;  // the root
+                tests = 0;
+                found = false;
+                sp = base = 0;
+                float tEntry;
+                const bool rootHit =
+                    slab_partial(p.rootMin[0], p.rootMin[1], p.rootMin[2], p.rootMax[0],
+                                 p.rootMax[1], p.rootMax[2], r, tEntry) &&
+                    (tEntry < tMax);
+                cur = rootHit ? p.rootRef : kDone;
+            }
+            if (exhausted && __ballot(cur != kDone) == 0ull) {
+                // nothing in flight and nothing left: fall through to the retire/break above
+                continue;
+            }
+        }
+
+        // ---- traverse until too few lanes of this wave still carry work ----------------
+        for (;;) {
+            // interior steps (lanes sitting on a leaf or finished wait here)
+            while (cur >= 0) {
+                const float4 *rec = p.wide + 4 * (long)cur;
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                const float4 q3 = rec[3];
+                const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
+                const int axis = __float_as_int(q3.z);
+                // aggregates.cpp:562-568: near child = second child iff dirIsNeg[axis]
+                const bool swap = axis == 0 ? r.negx : (axis == 1 ? r.negy : r.negz);
+                float t0, t1;
+                const bool e0 = slab_partial(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, t0);
+                const bool e1 = slab_partial(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, t1);
+                const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
+                const bool nearE = swap ? e1 : e0, farE = swap ? e0 : e1;
+                const float nearT = swap ? t1 : t0, farT = swap ? t0 : t1;
+                visited += 1;  // the near child is entered now
+                if (MODE == 1 || farE) {
+                    // push far child with its entry distance (+inf: box already missed)
+                    if (sp - base == W) {
+                        uint2 e;
+                        e.x = (unsigned)sref[base & (W - 1)][lane];
+                        e.y = __float_as_uint(skey[base & (W - 1)][lane]);
+                        spill[(long)base * spillStride] = e;
+                        ++base;
+                    }
+                    sref[sp & (W - 1)][lane] = farRef;
+                    skey[sp & (W - 1)][lane] = farE ? farT : __builtin_inff();
+                    ++sp;
+                } else if (MODE == 0) {
+                    visited += 1;  // the reference pops and rejects it later: same count
+                }
+                if (nearE && nearT < tMax) {
+                    cur = nearRef;
+                } else {
+                    // pop until a node whose box test passes with the current tMax
+                    cur = kDone;
+                    while (sp > 0) {
+                        --sp;
+                        int ref;
+                        float key;
+                        if (sp < base) {
+                            const uint2 e = spill[(long)sp * spillStride];
+                            base = sp;
+                            ref = (int)e.x;
+                            key = __uint_as_float(e.y);
+                        } else {
+                            ref = sref[sp & (W - 1)][lane];
+                            key = skey[sp & (W - 1)][lane];
+                        }
+                        if (MODE != 2) visited += 1;
+                        if (key < tMax) {
+                            cur = ref;
+                            break;
+                        }
+                    }
+                }
+            }
+            // leaf (cur < 0, cur != kDone)
+            if (cur != kDone) {
+                int slot = ~cur;
+                bool last;
+                do {
+                    const float4 s0 = p.prims[slot], s1 = p.prims[slot + 1], s2 = p.prims[slot + 2];
+                    const unsigned flags = __float_as_uint(s1.w);
+                    last = (flags & kPrimLast) != 0;
+                    tests += 1;
+                    bool hit;
+                    float x0, x1, x2, th;
+                    if (!(flags & kPrimPatch)) {
+                        hit = triangle_test(r, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                            {s2.x, s2.y, s2.z}, x0, x1, x2, th);
+                        slot += 3;
+                    } else {
+                        const float4 s3 = p.prims[slot + 3];
+                        x2 = 0.0f;
+                        hit = patch_test(r, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                         {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
+                        slot += 4;
+                    }
+                    if (hit) {
+                        if (MODE == 0) {
+                            hitPrim = __float_as_int(s0.w);
+                            hb0 = x0;
+                            hb1 = x1;
+                            hb2 = x2;
+                            tMax = th;
+                        } else {
+                            found = true;
+                            last = true;
+                        }
+                    }
+                } while (!last);
+                cur = kDone;
+                if (!(MODE != 0 && found)) {
+                    while (sp > 0) {
+                        --sp;
+                        int ref;
+                        float key;
+                        if (sp < base) {
+                            const uint2 e = spill[(long)sp * spillStride];
+                            base = sp;
+                            ref = (int)e.x;
+                            key = __uint_as_float(e.y);
+                        } else {
+                            ref = sref[sp & (W - 1)][lane];
+                            key = skey[sp & (W - 1)][lane];
+                        }
+                        if (MODE != 2) visited += 1;
+                        if (key < tMax) {
+                            cur = ref;
+                            break;
+                        }
+                    }
+                }
+            }
+            // refill when enough lanes went idle (or all did)
+            const int nActive = __popcll(__ballot(cur != kDone));
+            if (nActive == 0 || (!exhausted && nActive < p.refillBelow)) break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+template <int MODE>
+static hipError_t launch_mode(const TraceParams &p, int window, int blocks, hipStream_t stream) {
+    dim3 grid((unsigned)blocks), block(kBlockThreads);
+    switch (window) {
+    case 4: hipLaunchKernelGGL((trace_kernel<MODE, 4>), grid, block, 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((trace_kernel<MODE, 8>), grid, block, 0, stream, p); break;
+    case 16: hipLaunchKernelGGL((trace_kernel<MODE, 16>), grid, block, 0, stream, p); break;
+    case 32: hipLaunchKernelGGL((trace_kernel<MODE, 32>), grid, block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(int mode, const TraceParams &p, int window, int blocks,
+                        hipStream_t stream) {
+    switch (mode) {
+    case 0: return launch_mode<0>(p, window, blocks, stream);
+    case 1: return launch_mode<1>(p, window, blocks, stream);
+    case 2: return launch_mode<2>(p, window, blocks, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace nnbvh

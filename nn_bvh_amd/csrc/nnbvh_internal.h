@@ -1,0 +1,39 @@
+// nnbvh_internal.h — shared between the host-side pieces of libnnbvh_hip.so.
+#pragma once
+#include <cstdint>
+#include <string>
+
+namespace nnbvh {
+
+void set_error(const std::string &msg);
+
+// ---- device data layout (DESIGN.md §Data layout) -----------------------------------
+// One 64-byte record per INTERIOR node, holding both children's boxes, so that one
+// coalesced 64-B fetch decides both child visits (the reference does two dependent 32-B
+// LinearBVHNode fetches for the same decisions).  Records are numbered in the order
+// the interior nodes appear in the reference's DFS array.
+//   q0 = { c0.pmin.x, c0.pmin.y, c0.pmin.z, c0.pmax.x }
+//   q1 = { c0.pmax.y, c0.pmax.z, c1.pmin.x, c1.pmin.y }
+//   q2 = { c1.pmin.z, c1.pmax.x, c1.pmax.y, c1.pmax.z }
+//   q3 = { ref0, ref1, axis, 0 }   (int32 bit patterns)
+// c0 = the node at index+1 (first child), c1 = the node at secondChildOffset.
+// ref >= 0: interior record number; ref < 0: leaf, ~ref = first 16-B slot of its
+// primitives in the prim stream.
+struct WideNode {
+    float q[12];
+    int32_t ref0, ref1;
+    int32_t axis;
+    int32_t pad;
+};
+static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
+
+// Prim stream: 16-B slots, primitives in the reference's leaf order.
+//   triangle (3 slots): {p0.xyz, id} {p1.xyz, flags} {p2.xyz, 0}
+//   patch    (4 slots): {p00.xyz, id} {p10.xyz, flags} {p01.xyz, 0} {p11.xyz, 0}
+// flags bit0 = last primitive of its leaf, bit1 = bilinear patch.
+constexpr uint32_t kPrimLast = 1u;
+constexpr uint32_t kPrimPatch = 2u;
+
+constexpr int kMaxStack = 64;  // the reference's nodesToVisit[64], aggregates.cpp:538
+
+}  // namespace nnbvh

@@ -1,0 +1,91 @@
+"""ctypes binding of oracle/libnnbvh_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package (nn_bvh_amd/)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libnnbvh_oracle.so")
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
+    return ORACLE_LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ORACLE_DIR, "nnbvh_oracle.c")
+        if not os.path.exists(ORACLE_LIB) or os.path.getmtime(ORACLE_LIB) < os.path.getmtime(src):
+            build()
+        _lib = ctypes.CDLL(ORACLE_LIB)
+    return _lib
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def closest(nodes, prims, verts, rays, nthreads=1):
+    from nn_bvh_amd._lib import HIT_DTYPE
+    nodes, prims = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+    verts = np.ascontiguousarray(verts, np.float32)
+    rays = np.ascontiguousarray(rays)
+    hits = np.zeros(len(rays), HIT_DTYPE)
+    lib().orc_intersect_closest(_p(nodes), ctypes.c_int(len(nodes)), _p(prims), _p(verts), _p(rays),
+                                ctypes.c_int64(len(rays)), _p(hits), ctypes.c_int(nthreads))
+    return hits
+
+
+def any_hit(nodes, prims, verts, rays, nthreads=1):
+    nodes, prims = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+    verts = np.ascontiguousarray(verts, np.float32)
+    rays = np.ascontiguousarray(rays)
+    occ = np.zeros(len(rays), np.uint8)
+    vis = np.zeros(len(rays), np.int32)
+    tst = np.zeros(len(rays), np.int32)
+    lib().orc_intersect_any(_p(nodes), ctypes.c_int(len(nodes)), _p(prims), _p(verts), _p(rays),
+                            ctypes.c_int64(len(rays)), _p(occ), _p(vis), _p(tst),
+                            ctypes.c_int(nthreads))
+    return occ, vis, tst
+
+
+def brute_closest(prims, verts, rays):
+    from nn_bvh_amd._lib import HIT_DTYPE
+    prims = np.ascontiguousarray(prims)
+    verts = np.ascontiguousarray(verts, np.float32)
+    rays = np.ascontiguousarray(rays)
+    hits = np.zeros(len(rays), HIT_DTYPE)
+    lib().orc_brute_closest(_p(prims), ctypes.c_int(len(prims)), _p(verts), _p(rays),
+                            ctypes.c_int64(len(rays)), _p(hits))
+    return hits
+
+
+def leaf_batch(mode, inputs):
+    """mode in {'tri','blp','slab'}; inputs = golden record array (see tools/make_leaf_golden.py).
+    Returns (hit uint8[n], out float32[n,k])."""
+    r = np.ascontiguousarray(inputs, np.float32)
+    n = len(r)
+    o = np.ascontiguousarray(r[:, 0:3])
+    d = np.ascontiguousarray(r[:, 3:6])
+    t = np.ascontiguousarray(r[:, 6])
+    p = np.ascontiguousarray(r[:, 7:])
+    hit = np.zeros(n, np.uint8)
+    if mode == "tri":
+        out = np.zeros((n, 4), np.float32)
+        lib().orc_triangle_batch(_p(o), _p(d), _p(t), _p(p), n, _p(hit), _p(out))
+    elif mode == "blp":
+        out = np.zeros((n, 3), np.float32)
+        lib().orc_bilinear_patch_batch(_p(o), _p(d), _p(t), _p(p), n, _p(hit), _p(out))
+    else:
+        out = np.zeros((n, 0), np.float32)
+        lib().orc_slab_batch(_p(p), _p(o), _p(d), _p(t), n, _p(hit))
+    return hit, out
