@@ -41,13 +41,12 @@ def coincident_centroids(n=200, seed=0):
     """Many primitives with the same centroid -> one big leaf (> maxnodeprims), the
     coffee_maker 64-prim-leaf situation (aggregates.cpp:225-233)."""
     rng = np.random.default_rng(seed)
-    d = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
-    e = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
-    # triangles (c + d, c + e, c - d - e): centroid exactly c only approximately; use exact halves
-    d = np.round(d * 64) / 64
-    e = np.round(e * 64) / 64
+    # the builder's centroid is the BOUNDS centroid (aggregates.cpp:92): give every triangle the
+    # box [c - h, c + h] (h a multiple of 1/64, so .5*min + .5*max == c exactly)
+    h = (rng.integers(1, 64, size=(n, 3)) / 64.0).astype(np.float32)
+    w = (rng.integers(-63, 64, size=(n, 3)) / 64.0).astype(np.float32) * h
     c = np.array([1.0, 2.0, 3.0], np.float32)
-    verts = np.stack([c + d, c + e, c - d - e], 1).reshape(-1, 3).astype(np.float32)
+    verts = np.stack([c - h, c + h, c + w], 1).reshape(-1, 3).astype(np.float32)
     tri = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
     return verts, make_prims(tri)
 
