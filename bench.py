@@ -12,7 +12,8 @@ Multi-GPU: the BVH is replicated; each rank owns an interleaved
 image tiles (Morton-ordered ray chunks), traces only its tiles' rays — no data-path
 collective inside the timed steps — and the per-tile results are all-gathered once after the
 timed region (reported separately as allgather_ms).  Per-GPU work is fixed as N grows
-(weak scaling): with --gpus N the job traces N films' worth of tiles (sample index = rank).
+(weak scaling): with --gpus N the job is N samples per pixel and rank r traces its tiles of
+every sample, i.e. one film's worth of rays per GPU.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--scene crown] [--no-cpu-baseline]
 """
@@ -35,6 +36,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,8 +55,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="crown")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=400_000,
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="rays per class timed on the host cores for cpu_baseline")
+    ap.add_argument("--cpu-passes", type=int, default=5)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -220,19 +234,30 @@ def main():
         if allgather_ms is not None:
             result["allgather_ms"] = round(allgather_ms, 3)
 
-    # ---- CPU baseline: the oracle on this box's host cores, bounded sample, rank 0, N=1 only ----
+    # ---- CPU baseline: the oracle on this box's host cores; rank 0, N=1 only.  Bounded: the
+    # same three batches of one step, traced `passes` times after a warm-up pass (about 15
+    # core-seconds of work), on every core this process may use.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_binding as ob
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         n = min(args.cpu_sample, n_primary, len(bounce), len(shadow))
-        sel = np.random.default_rng(0).choice(min(n_primary, len(bounce), len(shadow)), n,
-                                              replace=False)
-        sel.sort()
-        t1 = time.perf_counter()
-        c1 = ob.closest(tree.nodes, tree.ordered_prims, verts, primary[sel], nthreads=cores)
-        c2 = ob.closest(tree.nodes, tree.ordered_prims, verts, bounce[sel], nthreads=cores)
-        o3, _, _ = ob.any_hit(tree.nodes, tree.ordered_prims, verts, shadow[sel], nthreads=cores)
-        cpu_s = time.perf_counter() - t1
+        sel = np.sort(np.random.default_rng(0).choice(min(n_primary, len(bounce), len(shadow)), n,
+                                                      replace=False))
+        batches = (primary[sel], bounce[sel], shadow[sel])
+
+        def cpu_pass():
+            a = ob.closest(tree.nodes, tree.ordered_prims, verts, batches[0], nthreads=cores)
+            b = ob.closest(tree.nodes, tree.ordered_prims, verts, batches[1], nthreads=cores)
+            c, _, _ = ob.any_hit(tree.nodes, tree.ordered_prims, verts, batches[2], nthreads=cores)
+            return a, b, c
+
+        c1, c2, o3 = cpu_pass()  # warm-up pass; its output is also the cross-check below
+        times = []
+        for _ in range(args.cpu_passes):
+            t1 = time.perf_counter()
+            cpu_pass()
+            times.append(time.perf_counter() - t1)
+        cpu_s = float(np.median(times))
         # the checker also checks: the sample must agree with what the GPU produced
         same = (c1.tobytes() == hits[sel].tobytes() and c2.tobytes() == bhits[sel].tobytes()
                 and (o3 == d_occ.cpu().numpy()[sel]).all())
@@ -241,8 +266,9 @@ def main():
             "unit": "Mray/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"{n} rays of each class (primary, bounce, shadow) of the same batches, "
-                      f"oracle/nnbvh_oracle.c on {cores} threads, {cpu_s:.1f}s",
+            "sample": f"{n} rays of each class (primary, bounce, shadow) of the step's own batches, "
+                      f"oracle/nnbvh_oracle.c on {cores} threads, median of {args.cpu_passes} "
+                      f"passes of {cpu_s:.2f}s",
             "matches_gpu": bool(same),
         }
     if rank == 0:

@@ -121,7 +121,9 @@ int nnbvh_intersect_any_device(nnbvh_scene *s, const void *d_rays, int64_t n, vo
                                void *d_nodes_visited, void *d_prim_tests, void *stream);
 
 /* tuning knobs (speed only, never results): "stack_window" (LDS entries per lane: 4,8,16,32),
- * "blocks_per_cu", "xcd_queues" (0/1).  Returns NNBVH_ERR_ARG for unknown keys. */
+ * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "refill_idle" (idle lanes of a wave that
+ * trigger a refill, 1..64), "prim_at" (lanes waiting on a leaf that trigger a primitive step,
+ * 1..64).  Returns NNBVH_ERR_ARG for unknown keys. */
 int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value);
 
 #ifdef __cplusplus

@@ -65,7 +65,8 @@ struct nnbvh_scene {
     int window = 8;
     int blocks_per_cu = 0;  // 0 = from the occupancy query
     int xcd_queues = 1;
-    int refill_below = 40;
+    int refill_idle = 16;
+    int prim_at = 24;
     int max_grid_threads = 0;
     std::mutex mu;
     std::map<hipStream_t, Workspace> workspaces;
@@ -267,7 +268,8 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
     if (const char *e = std::getenv("NNBVH_STACK_WINDOW")) nnbvh_scene_set_option(s, "stack_window", atoi(e));
     if (const char *e = std::getenv("NNBVH_BLOCKS_PER_CU")) nnbvh_scene_set_option(s, "blocks_per_cu", atoi(e));
     if (const char *e = std::getenv("NNBVH_XCD_QUEUES")) nnbvh_scene_set_option(s, "xcd_queues", atoi(e));
-    if (const char *e = std::getenv("NNBVH_REFILL_BELOW")) nnbvh_scene_set_option(s, "refill_below", atoi(e));
+    if (const char *e = std::getenv("NNBVH_REFILL_IDLE")) nnbvh_scene_set_option(s, "refill_idle", atoi(e));
+    if (const char *e = std::getenv("NNBVH_PRIM_AT")) nnbvh_scene_set_option(s, "prim_at", atoi(e));
     return s;
 }
 
@@ -342,12 +344,18 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
         s->blocks_per_cu = value;
     } else if (k == "xcd_queues") {
         s->xcd_queues = value ? 1 : 0;
-    } else if (k == "refill_below") {
+    } else if (k == "refill_idle") {
         if (value < 1 || value > 64) {
-            set_error("set_option: refill_below must be 1..64");
+            set_error("set_option: refill_idle must be 1..64");
             return NNBVH_ERR_ARG;
         }
-        s->refill_below = value;
+        s->refill_idle = value;
+    } else if (k == "prim_at") {
+        if (value < 1 || value > 64) {
+            set_error("set_option: prim_at must be 1..64");
+            return NNBVH_ERR_ARG;
+        }
+        s->prim_at = value;
     } else {
         set_error("set_option: unknown key");
         return NNBVH_ERR_ARG;
@@ -390,7 +398,8 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     p.n = (long)n;
     p.queue = w->queue;
     p.nQueues = s->xcd_queues ? kMaxQueues : 1;
-    p.refillBelow = s->refill_below;
+    p.refillIdle = s->refill_idle;
+    p.primAt = s->prim_at;
     p.spill = w->spill;
     if (!hip_ok(hipMemsetAsync(w->queue, 0, kMaxQueues * kQueueStrideWords * sizeof(unsigned),
                                stream),

@@ -25,7 +25,8 @@ struct TraceParams {
     long n;
     unsigned *queue;        // nQueues heads, kQueueStrideWords apart, zeroed before launch
     int nQueues;
-    int refillBelow;        // refill idle lanes once fewer than this many lanes are active
+    int refillIdle;         // retire + refill once this many lanes of a wave are idle
+    int primAt;             // run a primitive step once this many lanes wait on a leaf
     uint2 *spill;           // [kMaxStack][grid threads] overflow of the LDS stack window
 };
 

@@ -69,9 +69,11 @@ struct RayState {
 };
 
 // Slab test of util/vecmath.h:1573-1608 split in two: everything that does not involve
-// the ray's tMax is evaluated here (`early` = all of the reference's early-outs passed and
+// the ray's tMax is evaluated here (`early` = none of the reference's early-outs fired and
 // box tMax > 0), and the entry distance is returned so that the remaining conjunct
 // `tMin < raytMax` can be evaluated now (near child) or when the node is popped (far child).
+// Branch-free: the same comparisons on the same values as the reference, combined without
+// short-circuiting (values computed past a fired early-out are simply not used).
 DEV bool slab_partial(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                       const RayState &r, float &tEntry) {
     constexpr float widen = 1.0f + 2.0f * gamma_f(3);
@@ -81,17 +83,17 @@ DEV bool slab_partial(float mnx, float mny, float mnz, float mxx, float mxy, flo
     float tyMax = ((r.negy ? mny : mxy) - r.o.y) * r.inv.y;
     tMax *= widen;
     tyMax *= widen;
-    if (tMin > tyMax || tyMin > tMax) return false;
-    if (tyMin > tMin) tMin = tyMin;
-    if (tyMax < tMax) tMax = tyMax;
+    const bool out1 = (tMin > tyMax) | (tyMin > tMax);
+    tMin = (tyMin > tMin) ? tyMin : tMin;
+    tMax = (tyMax < tMax) ? tyMax : tMax;
     float tzMin = ((r.negz ? mxz : mnz) - r.o.z) * r.inv.z;
     float tzMax = ((r.negz ? mnz : mxz) - r.o.z) * r.inv.z;
     tzMax *= widen;
-    if (tMin > tzMax || tzMin > tMax) return false;
-    if (tzMin > tMin) tMin = tzMin;
-    if (tzMax < tMax) tMax = tzMax;
+    const bool out2 = (tMin > tzMax) | (tzMin > tMax);
+    tMin = (tzMin > tMin) ? tzMin : tMin;
+    tMax = (tzMax < tMax) ? tzMax : tMax;
     tEntry = tMin;
-    return tMax > 0.0f;
+    return !(out1 | out2) & (tMax > 0.0f);
 }
 
 // shapes.cpp:172-273
@@ -247,6 +249,14 @@ constexpr int kDone = (int)0x80000000;  // never a leaf ref: ~slot with slot = 0
 // MODE 0: closest hit (counts always)
 // MODE 1: any hit with exact node-visit / prim-test counts (pushes every far child)
 // MODE 2: any hit, occlusion flag only
+//
+// Every lane is a small state machine over `cur`:
+//     cur >= 0            an interior record to process        (interior step)
+//     cur <  0, != kDone  ~cur = prim-stream slot to test next (primitive step)
+//     cur == kDone        no ray (retire the finished one, fetch the next)
+// Each trip of the scheduling loop the WAVE picks one kind of step (wave-uniform, from
+// ballots) and the lanes in that state execute it; the others idle for that trip.  A ray's
+// own sequence of steps is exactly the reference's, so results cannot depend on the policy.
 template <int MODE, int W>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
     __shared__ int s_ref[kBlockThreads / 64][W][64];
@@ -277,36 +287,61 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
     bool found = false;  // MODE 1/2
     bool exhausted = false;
 
-    for (;;) {
-        // ---- retire finished rays, refill idle lanes ---------------------------------
-        const bool idle = (cur == kDone);
-        if (idle && ri >= 0) {
-            if (MODE == 0) {
-                float4 h0, h1;
-                h0.x = __int_as_float(hitPrim);
-                h0.y = tMax;
-                h0.z = hb0;
-                h0.w = hb1;
-                h1.x = hb2;
-                h1.y = __int_as_float(visited);
-                h1.z = __int_as_float(tests);
-                h1.w = 0.0f;
-                float4 *out = reinterpret_cast<float4 *>(p.hits) + 2 * ri;
-                out[0] = h0;
-                out[1] = h1;
+    // pop entries until one whose deferred box test passes with the current tMax
+    auto pop_next = [&]() -> int {
+        while (sp > 0) {
+            --sp;
+            int ref;
+            float key;
+            if (sp < base) {
+                const uint2 e = spill[(long)sp * spillStride];
+                base = sp;
+                ref = (int)e.x;
+                key = __uint_as_float(e.y);
             } else {
-                p.occluded[ri] = found ? 1 : 0;
-                if (MODE == 1) {
-                    if (p.visitedOut) p.visitedOut[ri] = visited;
-                    if (p.testsOut) p.testsOut[ri] = tests;
-                }
+                ref = sref[sp & (W - 1)][lane];
+                key = skey[sp & (W - 1)][lane];
             }
-            ri = -1;
+            if (MODE != 2) visited += 1;
+            if (key < tMax) return ref;
         }
-        const unsigned long long idleMask = __ballot(idle);
-        if (idleMask == ~0ull && exhausted) break;
-        if (!exhausted && idleMask != 0ull) {
-            const int nIdle = __popcll(idleMask);
+        return kDone;
+    };
+
+    for (;;) {
+        const bool isInt = cur >= 0;
+        const bool isIdle = cur == kDone;
+        const int nInt = __popcll(__ballot(isInt));
+        const unsigned long long idleMask = __ballot(isIdle);
+        const int nIdle = __popcll(idleMask);
+        const int nPrim = 64 - nInt - nIdle;
+
+        if (nIdle == 64 || (!exhausted && nIdle >= p.refillIdle)) {
+            // ---- retire finished rays, refill idle lanes -------------------------------
+            if (isIdle && ri >= 0) {
+                if (MODE == 0) {
+                    float4 h0, h1;
+                    h0.x = __int_as_float(hitPrim);
+                    h0.y = tMax;
+                    h0.z = hb0;
+                    h0.w = hb1;
+                    h1.x = hb2;
+                    h1.y = __int_as_float(visited);
+                    h1.z = __int_as_float(tests);
+                    h1.w = 0.0f;
+                    float4 *out = reinterpret_cast<float4 *>(p.hits) + 2 * ri;
+                    out[0] = h0;
+                    out[1] = h1;
+                } else {
+                    p.occluded[ri] = found ? 1 : 0;
+                    if (MODE == 1) {
+                        if (p.visitedOut) p.visitedOut[ri] = visited;
+                        if (p.testsOut) p.testsOut[ri] = tests;
+                    }
+                }
+                ri = -1;
+            }
+            if (exhausted) break;  // only reached with every lane idle
             long start = 0;
             for (;;) {  // find a queue with work left (own XCD's first, then steal)
                 const long qBegin = p.n * q / p.nQueues, qEnd = p.n * (q + 1) / p.nQueues;
@@ -318,7 +353,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                     const int rank = __builtin_amdgcn_mbcnt_hi(
                         (unsigned)(idleMask >> 32),
                         __builtin_amdgcn_mbcnt_lo((unsigned)idleMask, 0u));
-                    if (idle && start + rank < qEnd) ri = start + rank;
+                    if (isIdle && start + rank < qEnd) ri = start + rank;
                     break;
                 }
                 if (++queuesTried >= p.nQueues) {
@@ -327,7 +362,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                 }
                 q = (q + 1 == p.nQueues) ? 0 : q + 1;
             }
-            if (ri >= 0 && idle) {
+            if (ri >= 0 && isIdle) {
                 const float4 *in = reinterpret_cast<const float4 *>(p.rays) + 2 * ri;
                 const float4 r0 = in[0], r1 = in[1];
                 r.o = {r0.x, r0.y, r0.z};
@@ -351,16 +386,48 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                     (tEntry < tMax);
                 cur = rootHit ? p.rootRef : kDone;
             }
-            if (exhausted && __ballot(cur != kDone) == 0ull) {
-                // nothing in flight and nothing left: fall through to the retire/break above
-                continue;
-            }
+            continue;
         }
 
-        // ---- traverse until too few lanes of this wave still carry work ----------------
-        for (;;) {
-            // interior steps (lanes sitting on a leaf or finished wait here)
-            while (cur >= 0) {
+        if (nPrim >= p.primAt || nInt == 0) {
+            // ---- primitive step: lanes with a pending leaf test ONE primitive -----------
+            if (!isInt && !isIdle) {
+                const int slot = ~cur;
+                const float4 s0 = p.prims[slot], s1 = p.prims[slot + 1], s2 = p.prims[slot + 2];
+                const unsigned flags = __float_as_uint(s1.w);
+                tests += 1;
+                bool hit;
+                float x0, x1, x2, th;
+                int next;
+                if (!(flags & kPrimPatch)) {
+                    hit = triangle_test(r, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                        {s2.x, s2.y, s2.z}, x0, x1, x2, th);
+                    next = slot + 3;
+                } else {
+                    const float4 s3 = p.prims[slot + 3];
+                    x2 = 0.0f;
+                    hit = patch_test(r, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                     {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
+                    next = slot + 4;
+                }
+                if (hit) {
+                    if (MODE == 0) {
+                        hitPrim = __float_as_int(s0.w);
+                        hb0 = x0;
+                        hb1 = x1;
+                        hb2 = x2;
+                        tMax = th;
+                    } else {
+                        found = true;
+                    }
+                }
+                if (MODE != 0 && found) cur = kDone;            // aggregates.cpp:597-602
+                else if (flags & kPrimLast) cur = pop_next();   // leaf finished
+                else cur = ~next;
+            }
+        } else {
+            // ---- interior step ------------------------------------------------------------
+            if (isInt) {
                 const float4 *rec = p.wide + 4 * (long)cur;
                 const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
                 const float4 q3 = rec[3];
@@ -390,93 +457,9 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                 } else if (MODE == 0) {
                     visited += 1;  // the reference pops and rejects it later: same count
                 }
-                if (nearE && nearT < tMax) {
-                    cur = nearRef;
-                } else {
-                    // pop until a node whose box test passes with the current tMax
-                    cur = kDone;
-                    while (sp > 0) {
-                        --sp;
-                        int ref;
-                        float key;
-                        if (sp < base) {
-                            const uint2 e = spill[(long)sp * spillStride];
-                            base = sp;
-                            ref = (int)e.x;
-                            key = __uint_as_float(e.y);
-                        } else {
-                            ref = sref[sp & (W - 1)][lane];
-                            key = skey[sp & (W - 1)][lane];
-                        }
-                        if (MODE != 2) visited += 1;
-                        if (key < tMax) {
-                            cur = ref;
-                            break;
-                        }
-                    }
-                }
+                if (nearE && nearT < tMax) cur = nearRef;
+                else cur = pop_next();
             }
-            // leaf (cur < 0, cur != kDone)
-            if (cur != kDone) {
-                int slot = ~cur;
-                bool last;
-                do {
-                    const float4 s0 = p.prims[slot], s1 = p.prims[slot + 1], s2 = p.prims[slot + 2];
-                    const unsigned flags = __float_as_uint(s1.w);
-                    last = (flags & kPrimLast) != 0;
-                    tests += 1;
-                    bool hit;
-                    float x0, x1, x2, th;
-                    if (!(flags & kPrimPatch)) {
-                        hit = triangle_test(r, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                            {s2.x, s2.y, s2.z}, x0, x1, x2, th);
-                        slot += 3;
-                    } else {
-                        const float4 s3 = p.prims[slot + 3];
-                        x2 = 0.0f;
-                        hit = patch_test(r, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                         {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
-                        slot += 4;
-                    }
-                    if (hit) {
-                        if (MODE == 0) {
-                            hitPrim = __float_as_int(s0.w);
-                            hb0 = x0;
-                            hb1 = x1;
-                            hb2 = x2;
-                            tMax = th;
-                        } else {
-                            found = true;
-                            last = true;
-                        }
-                    }
-                } while (!last);
-                cur = kDone;
-                if (!(MODE != 0 && found)) {
-                    while (sp > 0) {
-                        --sp;
-                        int ref;
-                        float key;
-                        if (sp < base) {
-                            const uint2 e = spill[(long)sp * spillStride];
-                            base = sp;
-                            ref = (int)e.x;
-                            key = __uint_as_float(e.y);
-                        } else {
-                            ref = sref[sp & (W - 1)][lane];
-                            key = skey[sp & (W - 1)][lane];
-                        }
-                        if (MODE != 2) visited += 1;
-                        if (key < tMax) {
-                            cur = ref;
-                            break;
-                        }
-                    }
-                }
-            }
-            // refill when enough lanes went idle (or all did)
-            const int nActive = __popcll(__ballot(cur != kDone));
-            if (nActive == 0 || (!exhausted && nActive < p.refillBelow)) break;
         }
     }
 }

@@ -128,8 +128,8 @@ def test_results_independent_of_tuning_and_order():
     perm = np.random.default_rng(0).permutation(len(rays))
     shuffled = agg.Intersect(rays[perm])
     assert (shuffled.tobytes() == base[perm].tobytes())
-    for key, val in (("xcd_queues", 0), ("refill_below", 1), ("refill_below", 64),
-                     ("blocks_per_cu", 1), ("stack_window", 4)):
+    for key, val in (("xcd_queues", 0), ("refill_idle", 1), ("refill_idle", 64), ("prim_at", 1),
+                     ("prim_at", 64), ("blocks_per_cu", 1), ("stack_window", 4)):
         agg.set_option(key, val)
         assert agg.Intersect(rays).tobytes() == base.tobytes(), f"{key}={val} changed results"
     agg.close()

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of the scheduling knobs (speed only; results never change) on the
+bench workload.  Prints a table of Mray/s per ray class for every combination, median over
+rounds, all variants run round-robin in ONE process (cdna_hip_programming.md §5.4 rule 24)."""
+import argparse
+import itertools
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="crown")
+    ap.add_argument("--windows", default="8")
+    ap.add_argument("--blocks", default="0")
+    ap.add_argument("--refill", default="16")
+    ap.add_argument("--primat", default="24")
+    ap.add_argument("--xcd", default="1")
+    ap.add_argument("--rounds", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    from nn_bvh_amd import BVHAggregate, build_tree, make_prims, scene
+    from nn_bvh_amd._lib import HIT_DTYPE
+
+    verts, tris, source = scene.load_scene(args.scene)
+    tree = build_tree(make_prims(tris), verts)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+    cam = args.scene if args.scene in scene.CAMERAS else "crown"
+    primary = scene.camera_rays(cam, seed=1, sample=0)
+    hits = agg.Intersect(primary)
+    bounce = scene.bounce_rays(primary, hits, verts, tris, seed=2)
+    lo, hi = verts.min(0), verts.max(0)
+    shadow = scene.shadow_rays(primary, hits, verts, tris, lo + (hi - lo) * [0.3, 0.9, 0.3],
+                               lo + (hi - lo) * [0.7, 1.0, 0.7], seed=3)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def dev(a):
+        return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
+
+    d = {"primary": dev(primary), "bounce": dev(bounce), "shadow": dev(shadow)}
+    n = {"primary": len(primary), "bounce": len(bounce), "shadow": len(shadow)}
+    out = torch.empty(len(primary) * 32, dtype=torch.uint8, device="cuda")
+    combos = list(itertools.product([int(x) for x in args.windows.split(",")],
+                                    [int(x) for x in args.blocks.split(",")],
+                                    [int(x) for x in args.refill.split(",")],
+                                    [int(x) for x in args.xcd.split(",")],
+                                    [int(x) for x in args.primat.split(",")]))
+    times = {c: {k: [] for k in d} for c in combos}
+
+    def run(kind):
+        if kind == "shadow":
+            agg.intersect_p_device(d[kind].data_ptr(), out.data_ptr(), n[kind], stream=stream)
+        else:
+            agg.intersect_device(d[kind].data_ptr(), out.data_ptr(), n[kind], stream)
+
+    for rnd in range(args.rounds + 1):
+        for c in combos:
+            agg.set_option("stack_window", c[0])
+            agg.set_option("blocks_per_cu", c[1])
+            agg.set_option("refill_idle", c[2])
+            agg.set_option("xcd_queues", c[3])
+            agg.set_option("prim_at", c[4])
+            for kind in d:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                run(kind)
+                b.record()
+                torch.cuda.synchronize()
+                if rnd:  # round 0 = warm-up
+                    times[c][kind].append(a.elapsed_time(b))
+    print(f"# {source}; rays: {n}")
+    print("window blocks refill xcd primat | primary bounce shadow  Mray/s (median)")
+    for c in combos:
+        r = [n[k] / np.median(times[c][k]) / 1e3 for k in ("primary", "bounce", "shadow")]
+        print(f"{c[0]:6d} {c[1]:6d} {c[2]:6d} {c[3]:3d} {c[4]:6d} | {r[0]:7.1f} {r[1]:7.1f} {r[2]:7.1f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
