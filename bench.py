@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — Mray/s of the HIP BVH traversal path on the crown workload (BASELINE.json).
 
-One "step" = one sample-per-pixel wavefront pass over the crown film through the hot path,
-with all ray batches already resident in HBM:
-    closest-hit  over 1000x1400 primary rays        (BVHAggregate::Intersect)
+One "step" = one wavefront pass of --spp samples per pixel (default 8, each sample its own
+jitter stream) over the crown film through the hot path, all ray batches already resident in
+HBM, one launch per ray class:
+    closest-hit  over spp x 1000x1400 primary rays   (BVHAggregate::Intersect)
     closest-hit  over the diffuse-bounce rays of those hits
     any-hit      over the shadow rays of those hits  (BVHAggregate::IntersectP, tMax = 1-1e-4)
 value = rays traced by all ranks / wall time of K steps (max over ranks).
+
+Why 8 spp per launch: a launch's time is T(n) = ramp/drain + n / steady-state rate, and the
+drain is the dependent-load chain of the longest ray in the batch (crown: V up to ~600 nodes,
+about 0.55 ms) whatever n is (tools/scaling.py).  pbrt's wavefront integrator caps
+its queues at ~1 M samples (wavefront/integrator.cpp:230-234) for the memory of other GPUs;
+with 288 GB of HBM the natural MI355X design is fewer, larger launches (8 spp of the crown
+film = 11.2 M rays = 0.7 GB of ray + hit records).  --spp 1 reproduces the 1 M-ray regime.
 
 Multi-GPU: the BVH is replicated; each rank owns an interleaved set of 16x16
 image tiles (Morton-ordered ray chunks), traces only its tiles' rays — no data-path
 collective inside the timed steps — and the per-tile results are all-gathered once after the
 timed region (reported separately as allgather_ms).  Per-GPU work is fixed as N grows
 (weak scaling): with --gpus N the job is N samples per pixel and rank r traces its tiles of
-every sample, i.e. one film's worth of rays per GPU.
+every sample, i.e. --spp films' worth of rays per GPU.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--scene crown] [--no-cpu-baseline]
 """
@@ -54,6 +62,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="crown")
+    ap.add_argument("--spp", type=int, default=8, help="samples per pixel traced per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="rays per class timed on the host cores for cpu_baseline")
@@ -88,17 +97,17 @@ def main():
             f"build+upload {time.time() - t0:.1f}s; grid {agg.info['grid_blocks']} blocks, "
             f"window {agg.info['stack_window']}")
 
-    # ---- ray batches (synthetic, seeded).  The job is `world` samples per pixel of the film;
-    # rank r traces its interleaved 16x16 tiles of every sample, i.e. one film's worth of rays
-    # per GPU whatever N is (weak scaling).
+    # ---- ray batches (synthetic, seeded).  The job is `world * spp` samples per pixel of the
+    # film; rank r traces its interleaved 16x16 tiles of every sample, i.e. spp films' worth of
+    # rays per GPU whatever N is (weak scaling).
     cam_name = args.scene if args.scene in scene.CAMERAS else "crown"
     xres = scene.CAMERAS[cam_name][4]
     parts = []
-    for s_idx in range(world):
+    for s_idx in range(world * args.spp):
         rays_s, px, py = scene.camera_rays(cam_name, seed=1, sample=s_idx, return_pixels=True)
         parts.append(rays_s[shard.shard_indices(px, py, xres, world, rank)])
     primary = np.concatenate(parts)
-    shard_bytes = world * shard.shard_counts(px, py, xres, world) * 32  # hit bytes per rank
+    shard_bytes = world * args.spp * shard.shard_counts(px, py, xres, world) * 32  # hit bytes/rank
     n_primary = len(primary)
 
     def dev(a):
@@ -202,8 +211,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.scene}: 1 spp wavefront pass, primary+bounce closest-hit and "
-                            f"shadow any-hit, {rays_per_step} rays/step/GPU",
+                "workload": f"{args.scene}: {args.spp} spp wavefront pass per step, primary+bounce "
+                            f"closest-hit and shadow any-hit, {rays_per_step} rays/step/GPU",
+                "spp_per_step": args.spp,
                 "geometry": source,
                 "triangles": int(len(tris)),
                 "nodes": int(len(tree.nodes)),

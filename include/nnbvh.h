@@ -120,11 +120,19 @@ int nnbvh_intersect_closest_device(nnbvh_scene *s, const void *d_rays, int64_t n
 int nnbvh_intersect_any_device(nnbvh_scene *s, const void *d_rays, int64_t n, void *d_occluded,
                                void *d_nodes_visited, void *d_prim_tests, void *stream);
 
-/* tuning knobs (speed only, never results): "stack_window" (LDS entries per lane: 4,8,16,32),
- * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "refill_idle" (idle lanes of a wave that
- * trigger a refill, 1..64), "prim_at" (lanes waiting on a leaf that trigger a primitive step,
- * 1..64).  Returns NNBVH_ERR_ARG for unknown keys. */
+/* tuning knobs (speed only, never results): "stack_window" (LDS entries per lane: 4, 8, 16),
+ * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "prim_weight" / "refill_weight" (1..64:
+ * how much a lane waiting on a primitive test / an idle lane counts against a lane waiting on
+ * an interior node, which counts 16, when a wavefront picks its next step), "prefetch" (0/1: touch the children's cache lines ahead
+ * of use).  Returns
+ * NNBVH_ERR_ARG for unknown keys. */
 int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value);
+
+/* diagnostics: wavefront scheduling statistics accumulated since the last reset —
+ * out = {interior trips, interior lanes, primitive trips, primitive lanes, refill trips,
+ * refill lanes, and over the interior trips the sums of lanes waiting on an interior node,
+ * on a primitive, idle; one spare}.  All zero unless built with -DNNBVH_STATS. */
+int nnbvh_scene_sched_stats(nnbvh_scene *s, uint64_t out[10], int reset);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnnbvh_hip.so")
+# NNBVH_LIB selects a diagnostic build (e.g. libnnbvh_hip_stats.so); default is the product
+LIB_PATH = os.path.join(_HERE, os.environ.get("NNBVH_LIB", "libnnbvh_hip.so"))
 
 # numpy views of the wire structs (byte-identical to include/nnbvh.h)
 NODE_DTYPE = np.dtype([("pmin", "<f4", 3), ("pmax", "<f4", 3), ("offset", "<i4"),
@@ -23,7 +24,7 @@ EXPORTS = [
     "nnbvh_build_ordered_prims", "nnbvh_build_depth", "nnbvh_build_destroy",
     "nnbvh_scene_create", "nnbvh_scene_destroy", "nnbvh_scene_bounds", "nnbvh_scene_info",
     "nnbvh_intersect_closest", "nnbvh_intersect_any", "nnbvh_intersect_closest_device",
-    "nnbvh_intersect_any_device", "nnbvh_scene_set_option",
+    "nnbvh_intersect_any_device", "nnbvh_scene_set_option", "nnbvh_scene_sched_stats",
 ]
 
 _lib = None
@@ -74,6 +75,8 @@ def lib():
     L.nnbvh_intersect_any_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.nnbvh_scene_set_option.restype = i32
     L.nnbvh_scene_set_option.argtypes = [vp, ctypes.c_char_p, i32]
+    L.nnbvh_scene_sched_stats.restype = i32
+    L.nnbvh_scene_sched_stats.argtypes = [vp, vp, i32]
     _lib = L
     return L
 

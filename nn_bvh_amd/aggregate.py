@@ -123,6 +123,13 @@ class BVHAggregate:
         check(_lib.lib().nnbvh_scene_set_option(self._h, key.encode(), int(value)),
               f"set_option({key})")
 
+    def sched_stats(self, reset=True):
+        """Diagnostics (NNBVH_STATS builds): trips and lanes per step kind."""
+        out = np.zeros(10, np.uint64)
+        check(_lib.lib().nnbvh_scene_sched_stats(self._h, ptr(out), int(reset)), "sched_stats")
+        return dict(zip(("int_trips", "int_lanes", "prim_trips", "prim_lanes", "refill_trips",
+                         "refill_lanes", "i_nint", "i_nprim", "i_nidle"), (int(x) for x in out)))
+
     # -- reference interface ----------------------------------------------------------
     def Bounds(self):
         out = np.zeros(6, np.float32)

@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libnnbvh_hip.so")
 SOURCES = ["bvh_trace.hip", "bvh_capi.cpp", "bvh_build.cpp"]
 HEADERS = ["bvh_trace.h", "nnbvh_internal.h", os.path.join("..", "..", "include", "nnbvh.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 
 
 def _stale():
@@ -22,6 +22,17 @@ def _stale():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_stats(verbose=False):
+    """Diagnostic build with scheduling statistics compiled in (libnnbvh_hip_stats.so)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = os.path.join(HERE, "libnnbvh_hip_stats.so")
+    cmd = [hipcc] + FLAGS + ["-DNNBVH_STATS", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out
 
 
 def build(force=False, verbose=False):

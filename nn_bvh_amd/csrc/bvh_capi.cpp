@@ -65,8 +65,10 @@ struct nnbvh_scene {
     int window = 8;
     int blocks_per_cu = 0;  // 0 = from the occupancy query
     int xcd_queues = 1;
-    int refill_idle = 16;
-    int prim_at = 24;
+    int prim_weight = 24;
+    int refill_weight = 8;
+    unsigned long long *d_stats = nullptr;  // diagnostics (NNBVH_STATS builds)
+    int prefetch = 0;
     int max_grid_threads = 0;
     std::mutex mu;
     std::map<hipStream_t, Workspace> workspaces;
@@ -265,11 +267,14 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
         return nullptr;
     }
     s->device_bytes = wide_bytes + prim_bytes;
+    if (hipMalloc((void **)&s->d_stats, 16 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(s->d_stats, 0, 16 * sizeof(unsigned long long));
     if (const char *e = std::getenv("NNBVH_STACK_WINDOW")) nnbvh_scene_set_option(s, "stack_window", atoi(e));
     if (const char *e = std::getenv("NNBVH_BLOCKS_PER_CU")) nnbvh_scene_set_option(s, "blocks_per_cu", atoi(e));
     if (const char *e = std::getenv("NNBVH_XCD_QUEUES")) nnbvh_scene_set_option(s, "xcd_queues", atoi(e));
-    if (const char *e = std::getenv("NNBVH_REFILL_IDLE")) nnbvh_scene_set_option(s, "refill_idle", atoi(e));
-    if (const char *e = std::getenv("NNBVH_PRIM_AT")) nnbvh_scene_set_option(s, "prim_at", atoi(e));
+    if (const char *e = std::getenv("NNBVH_REFILL_WEIGHT")) nnbvh_scene_set_option(s, "refill_weight", atoi(e));
+    if (const char *e = std::getenv("NNBVH_PREFETCH")) nnbvh_scene_set_option(s, "prefetch", atoi(e));
+    if (const char *e = std::getenv("NNBVH_PRIM_WEIGHT")) nnbvh_scene_set_option(s, "prim_weight", atoi(e));
     return s;
 }
 
@@ -285,6 +290,7 @@ void nnbvh_scene_destroy(nnbvh_scene *s) {
     }
     (void)hipFree(s->d_wide);
     (void)hipFree(s->d_prims);
+    if (s->d_stats) (void)hipFree(s->d_stats);
     delete s;
 }
 
@@ -297,13 +303,18 @@ int nnbvh_scene_bounds(const nnbvh_scene *s, float out[6]) {
     return NNBVH_OK;
 }
 
-static int grid_blocks(nnbvh_scene *s) {
+// Persistent grid = what is resident at once (register/LDS limited), asked from the runtime
+// for the exact kernel instance.  The kernel needs no co-residency (no grid barrier; late
+// blocks just find less work in the queues), so a wrong answer costs speed, never results.
+static int grid_blocks(nnbvh_scene *s, int mode) {
     int per_cu = s->blocks_per_cu;
     if (per_cu <= 0) {
-        // LDS-limited residency: window * 2 KiB per block out of 160 KiB, at most 8 blocks
-        // (32 waves) per CU; the kernel needs no co-residency, so this is speed only.
-        per_cu = std::min(8, 160 / (s->window * 2));
-        per_cu = std::max(per_cu, 1);
+        TraceParams dummy{};
+        int occ = 0;
+        if (launch_trace(mode, dummy, s->window, s->prefetch, 0, nullptr, &occ) != hipSuccess ||
+            occ <= 0)
+            occ = std::max(1, std::min(8, 160 / (s->window * 2)));
+        per_cu = occ;
     }
     per_cu = std::min(per_cu, 8);
     return s->n_cus * per_cu;
@@ -318,8 +329,25 @@ int nnbvh_scene_info(const nnbvh_scene *s, int64_t out[6]) {
     out[1] = s->n_slots;
     out[2] = s->depth;
     out[3] = (int64_t)s->device_bytes;
-    out[4] = grid_blocks(const_cast<nnbvh_scene *>(s));
+    out[4] = grid_blocks(const_cast<nnbvh_scene *>(s), 0);
     out[5] = s->window;
+    return NNBVH_OK;
+}
+
+int nnbvh_scene_sched_stats(nnbvh_scene *s, uint64_t out[10], int reset) {
+    if (!s || !out) {
+        set_error("scene_sched_stats: null argument");
+        return NNBVH_ERR_ARG;
+    }
+    std::memset(out, 0, 10 * sizeof(uint64_t));
+    if (!s->d_stats) return NNBVH_OK;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    if (!hip_ok(hipDeviceSynchronize(), "scene_sched_stats") ||
+        !hip_ok(hipMemcpy(out, s->d_stats, 10 * sizeof(uint64_t), hipMemcpyDeviceToHost),
+                "scene_sched_stats"))
+        return NNBVH_ERR_DEVICE;
+    if (reset) (void)hipMemset(s->d_stats, 0, 16 * sizeof(unsigned long long));
     return NNBVH_OK;
 }
 
@@ -331,8 +359,8 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
     std::lock_guard<std::mutex> lock(s->mu);
     std::string k(key);
     if (k == "stack_window") {
-        if (value != 4 && value != 8 && value != 16 && value != 32) {
-            set_error("set_option: stack_window must be 4, 8, 16 or 32");
+        if (value != 4 && value != 8 && value != 16) {
+            set_error("set_option: stack_window must be 4, 8 or 16");
             return NNBVH_ERR_ARG;
         }
         s->window = value;
@@ -342,20 +370,22 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
             return NNBVH_ERR_ARG;
         }
         s->blocks_per_cu = value;
+    } else if (k == "prefetch") {
+        s->prefetch = value ? 1 : 0;
     } else if (k == "xcd_queues") {
         s->xcd_queues = value ? 1 : 0;
-    } else if (k == "refill_idle") {
+    } else if (k == "prim_weight") {
         if (value < 1 || value > 64) {
-            set_error("set_option: refill_idle must be 1..64");
+            set_error("set_option: prim_weight must be 1..64");
             return NNBVH_ERR_ARG;
         }
-        s->refill_idle = value;
-    } else if (k == "prim_at") {
+        s->prim_weight = value;
+    } else if (k == "refill_weight") {
         if (value < 1 || value > 64) {
-            set_error("set_option: prim_at must be 1..64");
+            set_error("set_option: refill_weight must be 1..64");
             return NNBVH_ERR_ARG;
         }
-        s->prim_at = value;
+        s->refill_weight = value;
     } else {
         set_error("set_option: unknown key");
         return NNBVH_ERR_ARG;
@@ -398,18 +428,20 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     p.n = (long)n;
     p.queue = w->queue;
     p.nQueues = s->xcd_queues ? kMaxQueues : 1;
-    p.refillIdle = s->refill_idle;
-    p.primAt = s->prim_at;
+    p.primWeight = s->prim_weight;
+    p.refillWeight = s->refill_weight;
+    p.stats = s->d_stats;
     p.spill = w->spill;
     if (!hip_ok(hipMemsetAsync(w->queue, 0, kMaxQueues * kQueueStrideWords * sizeof(unsigned),
                                stream),
                 "hipMemsetAsync(queue)"))
         return NNBVH_ERR_DEVICE;
     // never launch more threads than there are rays to start with (tiny batches)
-    int blocks = grid_blocks(s);
+    int blocks = grid_blocks(s, mode);
     const int64_t need = (n + kBlockThreads - 1) / kBlockThreads;
     if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
-    if (!hip_ok(launch_trace(mode, p, s->window, blocks, stream), "trace kernel launch"))
+    if (!hip_ok(launch_trace(mode, p, s->window, s->prefetch, blocks, stream, nullptr),
+                "trace kernel launch"))
         return NNBVH_ERR_DEVICE;
     return NNBVH_OK;
 }

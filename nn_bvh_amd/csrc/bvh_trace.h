@@ -25,12 +25,14 @@ struct TraceParams {
     long n;
     unsigned *queue;        // nQueues heads, kQueueStrideWords apart, zeroed before launch
     int nQueues;
-    int refillIdle;         // retire + refill once this many lanes of a wave are idle
-    int primAt;             // run a primitive step once this many lanes wait on a leaf
+    int primWeight;         // scheduling weight of a lane waiting on a primitive (interior = 16)
+    int refillWeight;       // scheduling weight of an idle lane (interior = 16)
+    unsigned long long *stats;  // NNBVH_STATS builds: trips/lanes per step kind; else unused
     uint2 *spill;           // [kMaxStack][grid threads] overflow of the LDS stack window
 };
 
-hipError_t launch_trace(int mode, const TraceParams &p, int window, int blocks,
-                        hipStream_t stream);
+// occupancy != nullptr: do not launch, report resident blocks per CU of that kernel instance
+hipError_t launch_trace(int mode, const TraceParams &p, int window, int prefetch, int blocks,
+                        hipStream_t stream, int *occupancy);
 
 }  // namespace nnbvh

@@ -64,8 +64,7 @@ DEV float maxabs(V3 v) { return max3(__builtin_fabsf(v.x), __builtin_fabsf(v.y),
 DEV float sel3(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 
 struct RayState {
-    V3 o, d, inv;
-    bool negx, negy, negz;
+    V3 o, d, inv;  // dirIsNeg[k] (aggregates.cpp:535) is recomputed as inv.k < 0 where needed
 };
 
 // Slab test of util/vecmath.h:1573-1608 split in two: everything that does not involve
@@ -77,17 +76,17 @@ struct RayState {
 DEV bool slab_partial(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                       const RayState &r, float &tEntry) {
     constexpr float widen = 1.0f + 2.0f * gamma_f(3);
-    float tMin = ((r.negx ? mxx : mnx) - r.o.x) * r.inv.x;
-    float tMax = ((r.negx ? mnx : mxx) - r.o.x) * r.inv.x;
-    float tyMin = ((r.negy ? mxy : mny) - r.o.y) * r.inv.y;
-    float tyMax = ((r.negy ? mny : mxy) - r.o.y) * r.inv.y;
+    float tMin = (((r.inv.x < 0.0f) ? mxx : mnx) - r.o.x) * r.inv.x;
+    float tMax = (((r.inv.x < 0.0f) ? mnx : mxx) - r.o.x) * r.inv.x;
+    float tyMin = (((r.inv.y < 0.0f) ? mxy : mny) - r.o.y) * r.inv.y;
+    float tyMax = (((r.inv.y < 0.0f) ? mny : mxy) - r.o.y) * r.inv.y;
     tMax *= widen;
     tyMax *= widen;
     const bool out1 = (tMin > tyMax) | (tyMin > tMax);
     tMin = (tyMin > tMin) ? tyMin : tMin;
     tMax = (tyMax < tMax) ? tyMax : tMax;
-    float tzMin = ((r.negz ? mxz : mnz) - r.o.z) * r.inv.z;
-    float tzMax = ((r.negz ? mnz : mxz) - r.o.z) * r.inv.z;
+    float tzMin = (((r.inv.z < 0.0f) ? mxz : mnz) - r.o.z) * r.inv.z;
+    float tzMax = (((r.inv.z < 0.0f) ? mnz : mxz) - r.o.z) * r.inv.z;
     tzMax *= widen;
     const bool out2 = (tMin > tzMax) | (tzMin > tMax);
     tMin = (tzMin > tMin) ? tzMin : tMin;
@@ -257,7 +256,11 @@ constexpr int kDone = (int)0x80000000;  // never a leaf ref: ~slot with slot = 0
 // Each trip of the scheduling loop the WAVE picks one kind of step (wave-uniform, from
 // ballots) and the lanes in that state execute it; the others idle for that trip.  A ray's
 // own sequence of steps is exactly the reference's, so results cannot depend on the policy.
-template <int MODE, int W>
+//
+// PF = 1: every interior step touches the cache lines its two children will be fetched from
+// as soon as their refs are known (speed only; compile-time so that the wait for the step's
+// own record loads does not have to cover the prefetches).
+template <int MODE, int W, int PF>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
     __shared__ int s_ref[kBlockThreads / 64][W][64];
     __shared__ float s_key[kBlockThreads / 64][W][64];
@@ -267,7 +270,6 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
     const int gtid = blockIdx.x * kBlockThreads + threadIdx.x;
     int(*sref)[64] = s_ref[wave];
     float(*skey)[64] = s_key[wave];
-    uint2 *spill = p.spill + gtid;
     const long spillStride = (long)gridDim.x * kBlockThreads;
 
     // which queue this wave drains first: its XCD's share of the batch (speed only)
@@ -279,28 +281,33 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
     }
     int queuesTried = 0;
 
+#ifdef NNBVH_STATS
+    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // trips/lanes per kind (I, P, R); [6..8] = sum nInt,nPrim,nIdle over I trips
+#endif
     RayState r;
     float tMax = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     int hitPrim = -1, visited = 0, tests = 0;
     int cur = kDone, sp = 0, base = 0;
-    long ri = -1;        // ray this lane carries, -1 = none
+    int ri = -1;         // ray this lane carries, -1 = none (n < 2^31 is enforced by the ABI)
     bool found = false;  // MODE 1/2
     bool exhausted = false;
+    unsigned pf0 = 0, pf1 = 0;  // landing registers of the child-record prefetches
 
     // pop entries until one whose deferred box test passes with the current tMax
     auto pop_next = [&]() -> int {
         while (sp > 0) {
             --sp;
-            int ref;
-            float key;
-            if (sp < base) {
-                const uint2 e = spill[(long)sp * spillStride];
+            int ref = sref[sp & (W - 1)][lane];  // always an LDS read (stale if spilled)
+            float key = skey[sp & (W - 1)][lane];
+            asm volatile("" : "+v"(ref), "+v"(key));  // keeps the two reads ds_read (no flat select)
+            if (sp < base) {                     // rare: the entry lives in the HBM spill array
+                const uint2 e = p.spill[(long)sp * spillStride + gtid];
                 base = sp;
                 ref = (int)e.x;
                 key = __uint_as_float(e.y);
-            } else {
-                ref = sref[sp & (W - 1)][lane];
-                key = skey[sp & (W - 1)][lane];
+                // complete the load inside this rare branch, so that the common path's join
+                // needs no vmcnt wait (which would also drain the in-flight prefetches)
+                asm volatile("" : "+v"(ref), "+v"(key));
             }
             if (MODE != 2) visited += 1;
             if (key < tMax) return ref;
@@ -316,7 +323,25 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
         const int nIdle = __popcll(idleMask);
         const int nPrim = 64 - nInt - nIdle;
 
-        if (nIdle == 64 || (!exhausted && nIdle >= p.refillIdle)) {
+        // Wave-uniform choice of this trip's step kind: the one that advances the most lanes
+        // per instruction issued.  A lane's weight says how cheap its step is relative to an
+        // interior step (weight 16): primitive tests and refills are longer, so they must
+        // gather more lanes before they are worth a trip.  All-idle always refills/retires.
+        const int sI = nInt * 16, sP = nPrim * p.primWeight;
+        const int sR = exhausted ? 0 : nIdle * p.refillWeight;
+#ifdef NNBVH_STATS
+        unsigned long long &stTrips = (nIdle == 64 || (sR > sI && sR > sP)) ? st[4]
+                                      : ((sP > sI || nInt == 0) ? st[2] : st[0]);
+        (&stTrips)[0] += 1;
+        (&stTrips)[1] += (nIdle == 64 || (sR > sI && sR > sP)) ? nIdle
+                         : ((sP > sI || nInt == 0) ? nPrim : nInt);
+        if (&stTrips == &st[0]) {
+            st[6] += nInt;
+            st[7] += nPrim;
+            st[8] += nIdle;
+        }
+#endif
+        if (nIdle == 64 || (sR > sI && sR > sP)) {
             // ---- retire finished rays, refill idle lanes -------------------------------
             if (isIdle && ri >= 0) {
                 if (MODE == 0) {
@@ -329,7 +354,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                     h1.y = __int_as_float(visited);
                     h1.z = __int_as_float(tests);
                     h1.w = 0.0f;
-                    float4 *out = reinterpret_cast<float4 *>(p.hits) + 2 * ri;
+                    float4 *out = reinterpret_cast<float4 *>(p.hits) + 2 * (long)ri;
                     out[0] = h0;
                     out[1] = h1;
                 } else {
@@ -341,7 +366,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                 }
                 ri = -1;
             }
-            if (exhausted) break;  // only reached with every lane idle
+            if (exhausted) break;  // only reached with every lane idle (sR == 0 otherwise)
             long start = 0;
             for (;;) {  // find a queue with work left (own XCD's first, then steal)
                 const long qBegin = p.n * q / p.nQueues, qEnd = p.n * (q + 1) / p.nQueues;
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                     const int rank = __builtin_amdgcn_mbcnt_hi(
                         (unsigned)(idleMask >> 32),
                         __builtin_amdgcn_mbcnt_lo((unsigned)idleMask, 0u));
-                    if (isIdle && start + rank < qEnd) ri = start + rank;
+                    if (isIdle && start + rank < qEnd) ri = (int)(start + rank);
                     break;
                 }
                 if (++queuesTried >= p.nQueues) {
@@ -363,16 +388,13 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                 q = (q + 1 == p.nQueues) ? 0 : q + 1;
             }
             if (ri >= 0 && isIdle) {
-                const float4 *in = reinterpret_cast<const float4 *>(p.rays) + 2 * ri;
+                const float4 *in = reinterpret_cast<const float4 *>(p.rays) + 2 * (long)ri;
                 const float4 r0 = in[0], r1 = in[1];
                 r.o = {r0.x, r0.y, r0.z};
                 tMax = r0.w;
                 r.d = {r1.x, r1.y, r1.z};
                 // aggregates.cpp:534-535
                 r.inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
-                r.negx = r.inv.x < 0;
-                r.negy = r.inv.y < 0;
-                r.negz = r.inv.z < 0;
                 hitPrim = -1;
                 hb0 = hb1 = hb2 = 0.0f;
                 visited = 1;  // the root
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
             continue;
         }
 
-        if (nPrim >= p.primAt || nInt == 0) {
+        if (sP > sI || nInt == 0) {
             // ---- primitive step: lanes with a pending leaf test ONE primitive -----------
             if (!isInt && !isIdle) {
                 const int slot = ~cur;
@@ -428,13 +450,31 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
         } else {
             // ---- interior step ------------------------------------------------------------
             if (isInt) {
+                // "use" of the words the previous interior step's prefetch loads returned: this
+                // is what keeps those loads alive in the compiled code (the values themselves
+                // are irrelevant); they landed long ago, so the wait emitted here is free
+                if (PF) asm volatile("" ::"v"(pf0), "v"(pf1));
                 const float4 *rec = p.wide + 4 * (long)cur;
-                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
                 const float4 q3 = rec[3];
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
                 const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
                 const int axis = __float_as_int(q3.z);
+                if (PF) {
+                    // Touch the cache line of BOTH children's next fetch (interior record or
+                    // first primitive slot) as soon as their refs are known, before the slab
+                    // arithmetic: the near child is fetched by this lane's next step, the far
+                    // child when the near subtree is exhausted.  The values are never used.
+                    const unsigned *a0 = ref0 >= 0
+                        ? reinterpret_cast<const unsigned *>(p.wide + 4 * (long)ref0)
+                        : reinterpret_cast<const unsigned *>(p.prims + (long)~ref0);
+                    const unsigned *a1 = ref1 >= 0
+                        ? reinterpret_cast<const unsigned *>(p.wide + 4 * (long)ref1)
+                        : reinterpret_cast<const unsigned *>(p.prims + (long)~ref1);
+                    pf0 = *a0;
+                    pf1 = *a1;
+                }
                 // aggregates.cpp:562-568: near child = second child iff dirIsNeg[axis]
-                const bool swap = axis == 0 ? r.negx : (axis == 1 ? r.negy : r.negz);
+                const bool swap = (axis == 0 ? r.inv.x : (axis == 1 ? r.inv.y : r.inv.z)) < 0.0f;
                 float t0, t1;
                 const bool e0 = slab_partial(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, t0);
                 const bool e1 = slab_partial(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, t1);
@@ -448,7 +488,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                         uint2 e;
                         e.x = (unsigned)sref[base & (W - 1)][lane];
                         e.y = __float_as_uint(skey[base & (W - 1)][lane]);
-                        spill[(long)base * spillStride] = e;
+                        p.spill[(long)base * spillStride + gtid] = e;
                         ++base;
                     }
                     sref[sp & (W - 1)][lane] = farRef;
@@ -462,28 +502,49 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
             }
         }
     }
+#ifdef NNBVH_STATS
+    if (lane == 0 && p.stats)
+        for (int k = 0; k < 10; ++k) atomicAdd(&p.stats[k], st[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------
-template <int MODE>
-static hipError_t launch_mode(const TraceParams &p, int window, int blocks, hipStream_t stream) {
-    dim3 grid((unsigned)blocks), block(kBlockThreads);
-    switch (window) {
-    case 4: hipLaunchKernelGGL((trace_kernel<MODE, 4>), grid, block, 0, stream, p); break;
-    case 8: hipLaunchKernelGGL((trace_kernel<MODE, 8>), grid, block, 0, stream, p); break;
-    case 16: hipLaunchKernelGGL((trace_kernel<MODE, 16>), grid, block, 0, stream, p); break;
-    case 32: hipLaunchKernelGGL((trace_kernel<MODE, 32>), grid, block, 0, stream, p); break;
-    default: return hipErrorInvalidValue;
+template <int MODE, int W, int PF>
+static hipError_t launch_one(const TraceParams &p, int blocks, hipStream_t stream, int *occupancy) {
+    if (occupancy) {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, trace_kernel<MODE, W, PF>,
+                                                            kBlockThreads, 0);
     }
+    hipLaunchKernelGGL((trace_kernel<MODE, W, PF>), dim3((unsigned)blocks), dim3(kBlockThreads), 0,
+                       stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(int mode, const TraceParams &p, int window, int blocks,
-                        hipStream_t stream) {
+template <int MODE, int PF>
+static hipError_t launch_window(const TraceParams &p, int window, int blocks, hipStream_t stream,
+                                int *occupancy) {
+    switch (window) {
+    case 4: return launch_one<MODE, 4, PF>(p, blocks, stream, occupancy);
+    case 8: return launch_one<MODE, 8, PF>(p, blocks, stream, occupancy);
+    case 16: return launch_one<MODE, 16, PF>(p, blocks, stream, occupancy);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MODE>
+static hipError_t launch_mode(const TraceParams &p, int window, int prefetch, int blocks,
+                              hipStream_t stream, int *occupancy) {
+    if (prefetch) return launch_window<MODE, 1>(p, window, blocks, stream, occupancy);
+    return launch_window<MODE, 0>(p, window, blocks, stream, occupancy);
+}
+
+// occupancy != nullptr: no launch, only report resident blocks per CU for that instance
+hipError_t launch_trace(int mode, const TraceParams &p, int window, int prefetch, int blocks,
+                        hipStream_t stream, int *occupancy) {
     switch (mode) {
-    case 0: return launch_mode<0>(p, window, blocks, stream);
-    case 1: return launch_mode<1>(p, window, blocks, stream);
-    case 2: return launch_mode<2>(p, window, blocks, stream);
+    case 0: return launch_mode<0>(p, window, prefetch, blocks, stream, occupancy);
+    case 1: return launch_mode<1>(p, window, prefetch, blocks, stream, occupancy);
+    case 2: return launch_mode<2>(p, window, prefetch, blocks, stream, occupancy);
     default: return hipErrorInvalidValue;
     }
 }

@@ -89,7 +89,7 @@ def test_big_leaves_and_single_leaf_tree():
     check_scene(verts, prims, rays, "equal", split="equal")
 
 
-@pytest.mark.parametrize("window", [4, 8, 16, 32])
+@pytest.mark.parametrize("window", [4, 8, 16])
 def test_stack_window_spill_is_exact(window):
     """A deep, skewed tree (equal-count splits of a long thin strip, leaves of 1) with rays
     along the strip keeps dozens of nodes pending: window 4 must spill to HBM and still agree."""
@@ -128,8 +128,9 @@ def test_results_independent_of_tuning_and_order():
     perm = np.random.default_rng(0).permutation(len(rays))
     shuffled = agg.Intersect(rays[perm])
     assert (shuffled.tobytes() == base[perm].tobytes())
-    for key, val in (("xcd_queues", 0), ("refill_idle", 1), ("refill_idle", 64), ("prim_at", 1),
-                     ("prim_at", 64), ("blocks_per_cu", 1), ("stack_window", 4)):
+    for key, val in (("xcd_queues", 0), ("refill_weight", 1), ("refill_weight", 64),
+                     ("prim_weight", 1), ("prim_weight", 64), ("blocks_per_cu", 1),
+                     ("stack_window", 4), ("prefetch", 0)):
         agg.set_option(key, val)
         assert agg.Intersect(rays).tobytes() == base.tobytes(), f"{key}={val} changed results"
     agg.close()

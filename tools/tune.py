@@ -18,10 +18,14 @@ def main():
     ap.add_argument("--scene", default="crown")
     ap.add_argument("--windows", default="8")
     ap.add_argument("--blocks", default="0")
-    ap.add_argument("--refill", default="16")
-    ap.add_argument("--primat", default="24")
+    ap.add_argument("--refill", default="8", help="refill_weight values")
+    ap.add_argument("--primat", default="8", help="prim_weight values")
+    ap.add_argument("--stats", action="store_true", help="print scheduling stats (NNBVH_STATS build)")
     ap.add_argument("--xcd", default="1")
+    ap.add_argument("--minwaves", default="0")
+    ap.add_argument("--prefetch", default="1")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--repeat", type=int, default=1, help="concatenate each batch this many times")
     args = ap.parse_args()
     import torch
     from nn_bvh_amd import BVHAggregate, build_tree, make_prims, scene
@@ -42,6 +46,8 @@ def main():
     def dev(a):
         return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
 
+    if args.repeat > 1:
+        primary, bounce, shadow = (np.concatenate([b] * args.repeat) for b in (primary, bounce, shadow))
     d = {"primary": dev(primary), "bounce": dev(bounce), "shadow": dev(shadow)}
     n = {"primary": len(primary), "bounce": len(bounce), "shadow": len(shadow)}
     out = torch.empty(len(primary) * 32, dtype=torch.uint8, device="cuda")
@@ -49,7 +55,9 @@ def main():
                                     [int(x) for x in args.blocks.split(",")],
                                     [int(x) for x in args.refill.split(",")],
                                     [int(x) for x in args.xcd.split(",")],
-                                    [int(x) for x in args.primat.split(",")]))
+                                    [int(x) for x in args.primat.split(",")],
+                                    [int(x) for x in args.minwaves.split(",")],
+                                    [int(x) for x in args.prefetch.split(",")]))
     times = {c: {k: [] for k in d} for c in combos}
 
     def run(kind):
@@ -62,9 +70,10 @@ def main():
         for c in combos:
             agg.set_option("stack_window", c[0])
             agg.set_option("blocks_per_cu", c[1])
-            agg.set_option("refill_idle", c[2])
+            agg.set_option("refill_weight", c[2])
             agg.set_option("xcd_queues", c[3])
-            agg.set_option("prim_at", c[4])
+            agg.set_option("prim_weight", c[4])
+            agg.set_option("prefetch", c[6])
             for kind in d:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
@@ -73,11 +82,22 @@ def main():
                 torch.cuda.synchronize()
                 if rnd:  # round 0 = warm-up
                     times[c][kind].append(a.elapsed_time(b))
+                if args.stats and rnd == args.rounds:
+                    st = agg.sched_stats()
+                    util = {k: round(st[k + "_lanes"] / max(1, st[k + "_trips"]) / 64, 3)
+                            for k in ("int", "prim", "refill")}
+                    print(f"  stats {c} {kind}: trips/ray I {st['int_trips'] * 64 / n[kind]:.1f} "
+                          f"P {st['prim_trips'] * 64 / n[kind]:.1f} R {st['refill_trips'] * 64 / n[kind]:.2f}"
+                          f" lanes/trip {util} during I trips: waiting-on-prim "
+                          f"{st['i_nprim'] / max(1, st['int_trips']):.1f} idle "
+                          f"{st['i_nidle'] / max(1, st['int_trips']):.1f}")
+                elif args.stats:
+                    agg.sched_stats()
     print(f"# {source}; rays: {n}")
-    print("window blocks refill xcd primat | primary bounce shadow  Mray/s (median)")
+    print("window blocks refillw xcd primw minw pf | primary bounce shadow  Mray/s (median)")
     for c in combos:
         r = [n[k] / np.median(times[c][k]) / 1e3 for k in ("primary", "bounce", "shadow")]
-        print(f"{c[0]:6d} {c[1]:6d} {c[2]:6d} {c[3]:3d} {c[4]:6d} | {r[0]:7.1f} {r[1]:7.1f} {r[2]:7.1f}", flush=True)
+        print(f"{c[0]:6d} {c[1]:6d} {c[2]:6d} {c[3]:3d} {c[4]:6d} {c[5]:4d} {c[6]:2d} | {r[0]:7.1f} {r[1]:7.1f} {r[2]:7.1f}", flush=True)
 
 
 if __name__ == "__main__":
