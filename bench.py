@@ -194,6 +194,17 @@ def main():
         allgather_ms = (time.perf_counter() - t1) * 1e3
         assert sum(g.numel() for g in gathered) == int(shard_bytes.sum())
 
+    # HBM-side traffic of the closest-hit kernel per launch, from the committed rocprofv3 PMC
+    # passes of this same command (profiles/; collected and corrected as MI355X_MICROARCH.md
+    # §HBM prescribes).  Only quoted when the profile was taken at the same --spp.
+    traffic = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+        if tr.get("spp") == args.spp and args.scene == "crown" and world == 1:
+            traffic = round(float(tr["bytes"]))
+    except (OSError, ValueError, KeyError):
+        pass
+
     result = None
     if rank == 0:
         value = total_rays_per_step * args.steps / elapsed / 1e6
@@ -234,7 +245,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "alg_bytes_per_launch": round(bytes_closest / 2),
                 "alg_bytes_per_ray": round(bytes_closest / (len(hits) + len(bhits)), 1),
                 "mean_nodes_visited": round(float(hits["nodes_visited"].mean()), 2),
                 "mean_prim_tests": round(float(hits["prim_tests"].mean()), 2),
