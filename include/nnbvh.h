@@ -48,7 +48,7 @@ typedef struct nnbvh_linear_node {
 } nnbvh_linear_node;
 
 #define NNBVH_PRIM_TRIANGLE 0       /* Triangle      (shapes.h:833-1192) */
-#define NNBVH_PRIM_BILINEAR_PATCH 1 /* BilinearPatch (shapes.h:1351-1539): v = p00,p10,p01,p11 */
+#define NNBVH_PRIM_BILINEAR_PATCH 1 /* BilinearPatch (shapes.h:1350-1539): v = p00,p10,p01,p11 */
 
 /* One entry of BVHAggregate::primitives: the shape handle flattened to global vertex
  * indices (Triangle{meshIndex,triIndex} -> mesh->vertexIndices[3*tri..], shapes.cpp:326-328). */

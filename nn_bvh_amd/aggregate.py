@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's aggregate interface for the accelerated path.
 
 `BVHAggregate` here has the reference's method names and argument meaning
-(/root/reference/src/pbrt/cpu/aggregates.h:27-68: Create / Bounds / Intersect / IntersectP),
+(/root/reference/src/pbrt/cpu/aggregates.h:28-70: Create / Bounds / Intersect / IntersectP),
 batched the way the wavefront caller batches them (wavefront/aggregate.cpp:34-68).  All
 arithmetic happens in libnnbvh_hip.so on the GPU; numpy/torch only carry buffers.
 """

@@ -1,0 +1,57 @@
+// Exercises include/nnbvh_aggregate.hpp the way a pbrt integrator would: per-ray Intersect /
+// IntersectP (Primitive interface) and the batched WavefrontAggregate-shaped calls, and checks
+// that the two agree with each other.  Built by tests/test_cpp_adapter.py with g++ against
+// libnnbvh_hip.so; run only where a GPU is present.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "nnbvh_aggregate.hpp"
+
+int main() {
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<float> U(-1.f, 1.f);
+    const int nTris = 500;
+    std::vector<float> verts;
+    std::vector<nnbvh_prim> prims;
+    for (int i = 0; i < nTris; ++i) {
+        float c[3] = {5 * U(rng), 5 * U(rng), 5 * U(rng)};
+        for (int k = 0; k < 3; ++k)
+            for (int a = 0; a < 3; ++a) verts.push_back(c[a] + 0.5f * U(rng));
+        prims.push_back(nnbvh_prim{NNBVH_PRIM_TRIANGLE, i, {3 * i, 3 * i + 1, 3 * i + 2, 0}});
+    }
+    nnbvh::HipBVHAggregate agg(prims, verts);  // sah, maxnodeprims 4, like BVHAggregate::Create
+    nnbvh::Bounds3f b = agg.Bounds();
+    if (!(b.pMin.x < b.pMax.x)) return 10;
+
+    const int nRays = 200;
+    std::vector<nnbvh_ray> rays(nRays);
+    for (auto &r : rays) {
+        float o[3] = {6 * U(rng), 6 * U(rng), 6 * U(rng)}, t[3] = {3 * U(rng), 3 * U(rng), 3 * U(rng)};
+        for (int a = 0; a < 3; ++a) {
+            r.o[a] = o[a];
+            r.d[a] = t[a] - o[a];
+        }
+        r.tmax = INFINITY;
+        r.time = 0;
+    }
+    std::vector<nnbvh_hit> hits(nRays);
+    std::vector<uint8_t> occ(nRays);
+    agg.IntersectClosest(rays.data(), nRays, hits.data());
+    agg.IntersectShadow(rays.data(), nRays, occ.data());
+    int nHit = 0;
+    for (int i = 0; i < nRays; ++i) {
+        nnbvh::Ray ray{{rays[i].o[0], rays[i].o[1], rays[i].o[2]},
+                       {rays[i].d[0], rays[i].d[1], rays[i].d[2]}, 0};
+        auto si = agg.Intersect(ray);
+        bool p = agg.IntersectP(ray);
+        if (si.has_value() != (hits[i].prim >= 0)) return 1;
+        if (si && (si->prim != hits[i].prim || std::memcmp(&si->tHit, &hits[i].t, 4))) return 2;
+        if (p != (occ[i] != 0) || p != si.has_value()) return 3;
+        nHit += si.has_value();
+    }
+    std::printf("adapter ok: %d rays, %d hits\n", nRays, nHit);
+    return nHit > 0 ? 0 : 4;
+}
