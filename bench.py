@@ -102,11 +102,10 @@ def main():
     # rays per GPU whatever N is (weak scaling).
     cam_name = args.scene if args.scene in scene.CAMERAS else "crown"
     xres = scene.CAMERAS[cam_name][4]
-    parts = []
-    for s_idx in range(world * args.spp):
-        rays_s, px, py = scene.camera_rays(cam_name, seed=1, sample=s_idx, return_pixels=True)
-        parts.append(rays_s[shard.shard_indices(px, py, xres, world, rank)])
-    primary = np.concatenate(parts)
+    _, px, py = scene.camera_rays(cam_name, seed=1, sample=0, return_pixels=True)
+    mine = shard.shard_indices(px, py, xres, world, rank)
+    primary = np.concatenate([scene.camera_rays(cam_name, seed=1, sample=s_idx, subset=mine)
+                              for s_idx in range(world * args.spp)])
     shard_bytes = world * args.spp * shard.shard_counts(px, py, xres, world) * 32  # hit bytes/rank
     n_primary = len(primary)
 

@@ -371,7 +371,11 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
         }
         s->blocks_per_cu = value;
     } else if (k == "prefetch") {
-        s->prefetch = value ? 1 : 0;
+        if (value < 0 || value > 2) {
+            set_error("set_option: prefetch must be 0, 1 or 2");
+            return NNBVH_ERR_ARG;
+        }
+        s->prefetch = value;
     } else if (k == "xcd_queues") {
         s->xcd_queues = value ? 1 : 0;
     } else if (k == "prim_weight") {

@@ -259,7 +259,8 @@ constexpr int kDone = (int)0x80000000;  // never a leaf ref: ~slot with slot = 0
 //
 // PF = 1: every interior step touches the cache lines its two children will be fetched from
 // as soon as their refs are known (speed only; compile-time so that the wait for the step's
-// own record loads does not have to cover the prefetches).
+// own record loads does not have to cover the prefetches).  PF = 2: only once the queues are
+// exhausted, i.e. while the launch drains and each remaining ray is a bare latency chain.
 template <int MODE, int W, int PF>
 __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
     __shared__ int s_ref[kBlockThreads / 64][W][64];
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                 const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
                 const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
                 const int axis = __float_as_int(q3.z);
-                if (PF) {
+                if (PF == 1 || (PF == 2 && exhausted)) {
                     // Touch the cache line of BOTH children's next fetch (interior record or
                     // first primitive slot) as soon as their refs are known, before the slab
                     // arithmetic: the near child is fetched by this lane's next step, the far
@@ -534,7 +535,8 @@ static hipError_t launch_window(const TraceParams &p, int window, int blocks, hi
 template <int MODE>
 static hipError_t launch_mode(const TraceParams &p, int window, int prefetch, int blocks,
                               hipStream_t stream, int *occupancy) {
-    if (prefetch) return launch_window<MODE, 1>(p, window, blocks, stream, occupancy);
+    if (prefetch == 1) return launch_window<MODE, 1>(p, window, blocks, stream, occupancy);
+    if (prefetch == 2) return launch_window<MODE, 2>(p, window, blocks, stream, occupancy);
     return launch_window<MODE, 0>(p, window, blocks, stream, occupancy);
 }
 

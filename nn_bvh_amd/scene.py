@@ -174,7 +174,16 @@ def load_scene(name):
 
 
 # ---------------------------------------------------------------------------------------
+_MORTON_CACHE = {}
+
+
 def _morton_order(xres, yres):
+    if (xres, yres) not in _MORTON_CACHE:
+        _MORTON_CACHE[(xres, yres)] = _morton_order_uncached(xres, yres)
+    return _MORTON_CACHE[(xres, yres)]
+
+
+def _morton_order_uncached(xres, yres):
     x, y = np.meshgrid(np.arange(xres, dtype=np.uint32), np.arange(yres, dtype=np.uint32),
                        indexing="xy")
     x, y = x.ravel(), y.ravel()
@@ -191,10 +200,13 @@ def _morton_order(xres, yres):
     return x[order].astype(np.float32), y[order].astype(np.float32)
 
 
-def camera_rays(name_or_cam, seed=1, sample=0, jitter=True, subsample=1, return_pixels=False):
+def camera_rays(name_or_cam, seed=1, sample=0, jitter=True, subsample=1, return_pixels=False,
+                subset=None):
     """Pinhole primary rays, one per pixel, in Morton (tile-coherent) pixel order.
     sample selects the jitter stream; subsample>1 keeps every k-th pixel in each axis.
-    With return_pixels also returns the integer pixel coordinates (px, py) of every ray."""
+    With return_pixels also returns the integer pixel coordinates (px, py) of every ray.
+    subset: indices into the Morton-ordered pixel list; only those rays are built (the jitter
+    of a pixel does not depend on the subset)."""
     cam = CAMERAS[name_or_cam] if isinstance(name_or_cam, str) else name_or_cam
     eye, look, up, fov, xres, yres = cam
     eye, look, up = (np.asarray(a, np.float64) for a in (eye, look, up))
@@ -205,6 +217,8 @@ def camera_rays(name_or_cam, seed=1, sample=0, jitter=True, subsample=1, return_
         jx, jy = rng.random(len(px)), rng.random(len(px))
     else:
         jx = jy = np.full(len(px), 0.5)
+    if subset is not None:
+        px, py, jx, jy = px[subset], py[subset], jx[subset], jy[subset]
     w = look - eye
     w /= np.linalg.norm(w)
     right = np.cross(w, up)  # pbrt LookAt is left-handed: right = up x dir, mirrored images are fine here
