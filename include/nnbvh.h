@@ -87,7 +87,7 @@ int nnbvh_device_count(void);
 
 /* ---- host-side tree construction (no GPU) ---------------------------------------- */
 #define NNBVH_SPLIT_SAH 0
-#define NNBVH_SPLIT_HLBVH 1 /* not implemented in this round: returns NULL */
+#define NNBVH_SPLIT_HLBVH 1
 #define NNBVH_SPLIT_MIDDLE 2
 #define NNBVH_SPLIT_EQUAL_COUNTS 3
 nnbvh_build *nnbvh_build_create(const nnbvh_prim *prims, int n_prims, const float *verts,

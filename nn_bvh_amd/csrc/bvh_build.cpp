@@ -7,6 +7,10 @@
 //   recursive SAH / Middle / EqualCounts :192-387 (buildRecursive; 12 buckets, leaf cost = n,
 //                                       split cost = 1/2 + sum/SA; leaves on zero surface
 //                                       area, single primitive or coincident centroids)
+//   HLBVH                              :389-503 (30-bit Morton codes of bounds centroids, 6-bit
+//                                       radix sort x5 :41-82, treelets on the top 12 bits,
+//                                       emitLBVH), :626-723 (buildUpperSAH over the treelets),
+//                                       util/math.h:99-119 (EncodeMorton3), :508-520 (FindInterval)
 //   DFS flattening to LinearBVHNode[]  :505-522 (flattenBVH; first child = index + 1)
 // The build is sequential, so leaf offsets are assigned in DFS order (the reference's
 // fetch_add order when no sub-tree is built in parallel, :209, :359-370); topology is
@@ -202,6 +206,195 @@ struct Builder {
     }
 };
 
+// ---- HLBVH (aggregates.cpp:389-503, 626-723) ----------------------------------------------
+struct MortonPrim {
+    int index;
+    uint32_t code;
+};
+
+inline uint32_t left_shift3(uint32_t x) {  // util/math.h:99-112
+    if (x == (1u << 10)) --x;
+    x = (x | (x << 16)) & 0b00000011000000000000000011111111u;
+    x = (x | (x << 8)) & 0b00000011000000001111000000001111u;
+    x = (x | (x << 4)) & 0b00000011000011000011000011000011u;
+    x = (x | (x << 2)) & 0b00001001001001001001001001001001u;
+    return x;
+}
+inline uint32_t encode_morton3(float x, float y, float z) {  // util/math.h:114-119
+    return (left_shift3((uint32_t)z) << 2) | (left_shift3((uint32_t)y) << 1) |
+           left_shift3((uint32_t)x);
+}
+
+void radix_sort(std::vector<MortonPrim> *v) {  // aggregates.cpp:41-82
+    std::vector<MortonPrim> temp(v->size());
+    constexpr int bitsPerPass = 6, nBits = 30, nPasses = nBits / bitsPerPass;
+    for (int pass = 0; pass < nPasses; ++pass) {
+        int lowBit = pass * bitsPerPass;
+        std::vector<MortonPrim> &in = (pass & 1) ? temp : *v;
+        std::vector<MortonPrim> &out = (pass & 1) ? *v : temp;
+        constexpr int nBuckets = 1 << bitsPerPass, bitMask = nBuckets - 1;
+        int count[nBuckets] = {0};
+        for (const MortonPrim &mp : in) ++count[(mp.code >> lowBit) & bitMask];
+        int outIndex[nBuckets];
+        outIndex[0] = 0;
+        for (int i = 1; i < nBuckets; ++i) outIndex[i] = outIndex[i - 1] + count[i - 1];
+        for (const MortonPrim &mp : in) out[outIndex[(mp.code >> lowBit) & bitMask]++] = mp;
+    }
+    if (nPasses & 1) std::swap(*v, temp);
+}
+
+template <typename Pred>
+size_t find_interval(size_t sz, const Pred &pred) {  // util/math.h:508-520
+    long size = (long)sz - 2, first = 1;
+    while (size > 0) {
+        size_t half = (size_t)size >> 1, middle = first + half;
+        bool r = pred(middle);
+        first = r ? (long)middle + 1 : first;
+        size = r ? size - (long)(half + 1) : (long)half;
+    }
+    long lo = first - 1, hi = (long)sz - 2;
+    return (size_t)(lo < 0 ? 0 : (lo > hi ? hi : lo));
+}
+
+struct HLBuilder {
+    Builder &b;  // node pool, ordered prims, counters
+    const std::vector<BuildPrim> &bp;
+    std::string error;
+
+    BuildNode *emit(const MortonPrim *mp, int n, int bitIndex) {  // emitLBVH, :451-503
+        if (bitIndex == -1 || n < b.max_prims) {
+            BuildNode *node = b.alloc();
+            ++b.total_nodes;
+            Box bounds;
+            int first = b.ordered_off;
+            b.ordered_off += n;
+            for (int i = 0; i < n; ++i) {
+                b.ordered[first + i] = b.prims[mp[i].index];
+                bounds.add(bp[mp[i].index].bounds);
+            }
+            node->first = first;
+            node->n = n;
+            node->bounds = bounds;
+            return node;
+        }
+        uint32_t mask = 1u << bitIndex;
+        if ((mp[0].code & mask) == (mp[n - 1].code & mask)) return emit(mp, n, bitIndex - 1);
+        int split = (int)find_interval((size_t)n, [&](size_t i) {
+            return (mp[0].code & mask) == (mp[i].code & mask);
+        });
+        ++split;
+        BuildNode *node = b.alloc();
+        ++b.total_nodes;
+        node->child[0] = emit(mp, split, bitIndex - 1);
+        node->child[1] = emit(mp + split, n - split, bitIndex - 1);
+        node->bounds = Box();
+        node->bounds.add(node->child[0]->bounds);
+        node->bounds.add(node->child[1]->bounds);
+        node->axis = bitIndex % 3;
+        node->n = 0;
+        return node;
+    }
+
+    BuildNode *upper(std::vector<BuildNode *> &roots, int start, int end) {  // buildUpperSAH
+        if (!error.empty()) return nullptr;
+        int n = end - start;
+        if (n == 1) return roots[start];
+        BuildNode *node = b.alloc();
+        ++b.total_nodes;
+        Box bounds, cb;
+        for (int i = start; i < end; ++i) bounds.add(roots[i]->bounds);
+        for (int i = start; i < end; ++i) {
+            const Box &rb = roots[i]->bounds;
+            float c[3] = {(rb.mn[0] + rb.mx[0]) * 0.5f, (rb.mn[1] + rb.mx[1]) * 0.5f,
+                          (rb.mn[2] + rb.mx[2]) * 0.5f};
+            cb.add(c);
+        }
+        int dim = cb.max_dimension();
+        if (cb.mx[dim] == cb.mn[dim]) {  // the reference CHECK_NE-aborts here (:650)
+            error = "HLBVH: treelet centroids coincide (the reference aborts on this input)";
+            return nullptr;
+        }
+        constexpr int nBuckets = 12;
+        int count[nBuckets] = {0};
+        Box bb[nBuckets];
+        auto bucket_of = [&cb, dim](const BuildNode *nd) {
+            float centroid = (nd->bounds.mn[dim] + nd->bounds.mx[dim]) * 0.5f;
+            int k = nBuckets * ((centroid - cb.mn[dim]) / (cb.mx[dim] - cb.mn[dim]));
+            if (k == nBuckets) k = nBuckets - 1;
+            return k;
+        };
+        for (int i = start; i < end; ++i) {
+            int k = bucket_of(roots[i]);
+            count[k]++;
+            bb[k].add(roots[i]->bounds);
+        }
+        float cost[nBuckets - 1];
+        for (int i = 0; i < nBuckets - 1; ++i) {
+            Box b0, b1;
+            int c0 = 0, c1 = 0;
+            for (int j = 0; j <= i; ++j) {
+                b0.add(bb[j]);
+                c0 += count[j];
+            }
+            for (int j = i + 1; j < nBuckets; ++j) {
+                b1.add(bb[j]);
+                c1 += count[j];
+            }
+            cost[i] = .125f + (c0 * b0.surface_area() + c1 * b1.surface_area()) /
+                                  bounds.surface_area();
+        }
+        float min_cost = cost[0];
+        int best = 0;
+        for (int i = 1; i < nBuckets - 1; ++i)
+            if (cost[i] < min_cost) {
+                min_cost = cost[i];
+                best = i;
+            }
+        BuildNode **pmid = std::partition(&roots[start], &roots[end - 1] + 1,
+                                          [&](const BuildNode *nd) { return bucket_of(nd) <= best; });
+        int mid = (int)(pmid - &roots[0]);
+        if (mid <= start || mid >= end) {  // CHECK_GT / CHECK_LT in the reference (:715-716)
+            error = "HLBVH: degenerate upper-level SAH split (the reference aborts on this input)";
+            return nullptr;
+        }
+        node->child[0] = upper(roots, start, mid);
+        node->child[1] = upper(roots, mid, end);
+        if (!node->child[0] || !node->child[1]) return nullptr;
+        node->bounds = Box();
+        node->bounds.add(node->child[0]->bounds);
+        node->bounds.add(node->child[1]->bounds);
+        node->axis = dim;
+        node->n = 0;
+        return node;
+    }
+
+    BuildNode *build() {  // buildHLBVH, :389-449
+        Box cb;
+        for (const BuildPrim &p : bp) {
+            float c[3] = {p.centroid(0), p.centroid(1), p.centroid(2)};
+            cb.add(c);
+        }
+        std::vector<MortonPrim> mp(bp.size());
+        for (size_t i = 0; i < bp.size(); ++i) {
+            constexpr int mortonScale = 1 << 10;
+            float c[3] = {bp[i].centroid(0), bp[i].centroid(1), bp[i].centroid(2)};
+            mp[i].index = (int)bp[i].index;
+            mp[i].code = encode_morton3(cb.offset(c, 0) * mortonScale, cb.offset(c, 1) * mortonScale,
+                                        cb.offset(c, 2) * mortonScale);
+        }
+        radix_sort(&mp);
+        std::vector<BuildNode *> roots;
+        for (size_t start = 0, end = 1; end <= mp.size(); ++end) {
+            const uint32_t mask = 0b00111111111111000000000000000000u;
+            if (end == mp.size() || ((mp[start].code & mask) != (mp[end].code & mask))) {
+                roots.push_back(emit(&mp[start], (int)(end - start), 29 - 12));
+                start = end;
+            }
+        }
+        return upper(roots, 0, (int)roots.size());
+    }
+};
+
 int flatten(const BuildNode *node, nnbvh_linear_node *out, int *offset, int depth, int *max_depth) {
     nnbvh_linear_node *ln = &out[*offset];
     std::memcpy(ln->pmin, node->bounds.mn, 12);
@@ -238,12 +431,8 @@ nnbvh_build *nnbvh_build_create(const nnbvh_prim *prims, int n_prims, const floa
         nnbvh::set_error("nnbvh_build_create: empty primitive or vertex array");
         return nullptr;
     }
-    if (split_method == NNBVH_SPLIT_HLBVH) {
-        nnbvh::set_error("nnbvh_build_create: HLBVH split method is not implemented");
-        return nullptr;
-    }
     if (split_method != NNBVH_SPLIT_SAH && split_method != NNBVH_SPLIT_MIDDLE &&
-        split_method != NNBVH_SPLIT_EQUAL_COUNTS) {
+        split_method != NNBVH_SPLIT_EQUAL_COUNTS && split_method != NNBVH_SPLIT_HLBVH) {
         nnbvh::set_error("nnbvh_build_create: unknown split method");
         return nullptr;
     }
@@ -269,7 +458,17 @@ nnbvh_build *nnbvh_build_create(const nnbvh_prim *prims, int n_prims, const floa
     b.max_prims = std::min(255, max_prims_in_node);  // aggregates.cpp:142
     b.method = split_method;
     b.ordered.resize((size_t)n_prims);
-    BuildNode *root = b.build(bp.data(), bp.size());
+    BuildNode *root;
+    if (split_method == NNBVH_SPLIT_HLBVH) {
+        HLBuilder hl{b, bp, {}};
+        root = hl.build();
+        if (!root) {
+            nnbvh::set_error("nnbvh_build_create: " + hl.error);
+            return nullptr;
+        }
+    } else {
+        root = b.build(bp.data(), bp.size());
+    }
     auto *out = new nnbvh_build;
     out->nodes.resize((size_t)b.total_nodes);
     int off = 0;

@@ -45,11 +45,16 @@ def check_tree(tree, prims, verts, max_prims):
     assert (covered == 1).all()
 
 
-@pytest.mark.parametrize("split,max_prims", [("sah", 4), ("sah", 1), ("middle", 4), ("equal", 2)])
+@pytest.mark.parametrize("split,max_prims", [("sah", 4), ("sah", 1), ("middle", 4), ("equal", 2),
+                                             ("hlbvh", 4), ("hlbvh", 1)])
 def test_builder_invariants(nnbvh_lib, split, max_prims):
     verts, prims = ss.random_soup(700, 150, 4)
     tree = build_tree(prims, verts, max_prims, split)
     check_tree(tree, prims, verts, max_prims)
+    if split == "hlbvh":
+        # emitLBVH makes a leaf when nPrimitives < maxPrimsInNode (strictly), aggregates.cpp:459
+        leaves = tree.nodes[tree.nodes["nprims"] > 0]
+        assert len(leaves) > 10
     if split == "sah" and max_prims == 4:
         # SAH never makes a leaf above maxnodeprims unless centroids coincide (aggregates.cpp:337)
         assert tree.nodes["nprims"].max() <= 4
@@ -72,8 +77,12 @@ def test_builder_is_deterministic_and_rejects_bad_input(nnbvh_lib):
         build_tree(bad, verts)
     with pytest.raises(NNBVHError, match="unknown"):
         build_tree(prims, verts, split_method="kdtree")
-    with pytest.raises(NNBVHError, match="HLBVH"):
-        build_tree(prims, verts, split_method="hlbvh")
+    h1, h2 = build_tree(prims, verts, 4, "hlbvh"), build_tree(prims, verts, 4, "hlbvh")
+    assert h1.nodes.tobytes() == h2.nodes.tobytes()
+    # all primitives in one point: the reference's buildUpperSAH / emitLBVH degenerate cases
+    same = make_prims(np.zeros((5, 3), np.int32) + np.arange(3, dtype=np.int32))
+    t = build_tree(same, verts, 4, "hlbvh")          # identical Morton codes -> a single leaf
+    assert len(t.nodes) == 1 and t.nodes["nprims"][0] == 5
     with pytest.raises(NNBVHError, match="empty"):
         build_tree(prims[:0], verts)
 

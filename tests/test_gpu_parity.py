@@ -87,6 +87,7 @@ def test_big_leaves_and_single_leaf_tree():
     check_scene(verts, prims, rays, "maxprims255", max_prims=255)
     check_scene(verts, prims, rays, "middle", split="middle")
     check_scene(verts, prims, rays, "equal", split="equal")
+    check_scene(verts, prims, rays, "hlbvh", split="hlbvh")
 
 
 @pytest.mark.parametrize("window", [4, 8, 16])
