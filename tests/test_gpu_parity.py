@@ -163,7 +163,7 @@ def test_degenerate_rays_nan_inf_zero_direction():
     check_scene(verts, prims, rays, "degenerate rays")
 
 
-@pytest.mark.parametrize("name", ["coffee_maker", "bathroom", "crown"])
+@pytest.mark.parametrize("name", ["killeroos", "coffee_maker", "bathroom", "crown"])
 def test_reference_scene_blobs_full_size(name):
     """Full-size scenes (when the git-ignored blob travelled): oracle parity on a sample of each
     ray class, plus size-independent properties on the full primary batch."""
