@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="crown")
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel traced per step")
+    ap.add_argument("--tree", default="sah", choices=["sah", "hlbvh", "middle", "equal", "nn"],
+                    help="tree builder: pbrt split methods, or nn = greedy-SAH top levels of "
+                         "machine_learning/nn_BVH.py finished by SAH and baked (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="rays per class timed on the host cores for cpu_baseline")
@@ -90,8 +93,15 @@ def main():
     t0 = time.time()
     verts, tris, source = scene.load_scene(args.scene)
     prims = make_prims(tris)
-    tree = build_tree(prims, verts)
+    if args.tree == "nn":
+        from nn_bvh_amd import nn_tree
+        from nn_bvh_amd.aggregate import BuiltTree
+        (nn_nodes, nn_ordered), _ = nn_tree.greedy_sah_tree(verts, tris, levels=4)
+        tree = BuiltTree(nn_nodes, nn_ordered, -1)
+    else:
+        tree = build_tree(prims, verts, 4, args.tree)
     agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, device=local_rank)
+    tree.depth = agg.info["depth"]
     if rank == 0:
         log(f"[bench] scene: {source}; {len(tris)} tris, {len(tree.nodes)} nodes, depth {tree.depth}; "
             f"build+upload {time.time() - t0:.1f}s; grid {agg.info['grid_blocks']} blocks, "
@@ -225,6 +235,7 @@ def main():
                             f"closest-hit and shadow any-hit, {rays_per_step} rays/step/GPU",
                 "spp_per_step": args.spp,
                 "geometry": source,
+                "tree": args.tree,
                 "triangles": int(len(tris)),
                 "nodes": int(len(tree.nodes)),
                 "rays_primary": int(n_primary),
