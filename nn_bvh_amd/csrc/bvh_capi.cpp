@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -141,6 +142,25 @@ static bool validate_tree(const nnbvh_linear_node *nodes, int n_nodes, int n_pri
     return true;
 }
 
+// The reference's degenerate-triangle test (shapes.cpp:176-177) with its exact float32
+// arithmetic: Cross via DifferenceOfProducts (util/vecmath.h:999-1004, util/math.h:569-575,
+// fmaf where the reference has FMA), LengthSquared as x*x + y*y + z*z (vecmath.h:948-950).
+// This translation unit is compiled with -ffp-contract=off.
+static float dop_host(float a, float b, float c, float d) {
+    float cd = c * d;
+    float diff = std::fma(a, b, -cd);
+    float err = std::fma(-c, d, cd);
+    return diff + err;
+}
+static bool triangle_is_degenerate(const float *p0, const float *p1, const float *p2) {
+    float v[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    float w[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    float cx = dop_host(v[1], w[2], v[2], w[1]);
+    float cy = dop_host(v[2], w[0], v[0], w[2]);
+    float cz = dop_host(v[0], w[1], v[1], w[0]);
+    return cx * cx + cy * cy + cz * cz == 0.0f;
+}
+
 static void put3(float *q, int at, const float *v) {
     q[at] = v[0];
     q[at + 1] = v[1];
@@ -203,6 +223,10 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
         for (int j = 0; j < nv; ++j) put3(s, 4 * j, verts + 3 * (size_t)p.v[j]);
         uint32_t flags = (leaf_last[(size_t)k] ? kPrimLast : 0u) |
                          (p.kind == NNBVH_PRIM_BILINEAR_PATCH ? kPrimPatch : 0u);
+        if (p.kind == NNBVH_PRIM_TRIANGLE &&
+            triangle_is_degenerate(verts + 3 * (size_t)p.v[0], verts + 3 * (size_t)p.v[1],
+                                   verts + 3 * (size_t)p.v[2]))
+            flags |= kPrimDegenerate;
         std::memcpy(&s[3], &p.id, 4);
         std::memcpy(&s[7], &flags, 4);
     }

@@ -64,8 +64,30 @@ DEV float maxabs(V3 v) { return max3(__builtin_fabsf(v.x), __builtin_fabsf(v.y),
 DEV float sel3(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 
 struct RayState {
-    V3 o, d, inv;  // dirIsNeg[k] (aggregates.cpp:535) is recomputed as inv.k < 0 where needed
+    V3 o, inv;  // dirIsNeg[k] (aggregates.cpp:535) is recomputed as inv.k < 0 where needed
+                // (the direction itself is cold state: only the patch test reads it, from LDS)
+    // The part of IntersectTriangle that depends on the ray only (shapes.cpp:186-201): the
+    // permutation (kz = largest |d| component) and the shear Sx, Sy, Sz.  The reference
+    // recomputes them for every triangle; computed once per ray they are the same floats.
+    float sx, sy, sz;
+    int kz;
 };
+
+DEV void ray_shear(RayState &r, V3 d) {
+    float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);  // vecmath.h:453-455
+    int kx = kz + 1;
+    if (kx == 3) kx = 0;
+    int ky = kx + 1;
+    if (ky == 3) ky = 0;
+    float dx = kx == 0 ? d.x : (kx == 1 ? d.y : d.z);
+    float dy = ky == 0 ? d.x : (ky == 1 ? d.y : d.z);
+    float dz = kz == 0 ? d.x : (kz == 1 ? d.y : d.z);
+    r.sx = -dx / dz;
+    r.sy = -dy / dz;
+    r.sz = 1.0f / dz;
+    r.kz = kz;
+}
 
 // Slab test of util/vecmath.h:1573-1608 split in two: everything that does not involve
 // the ray's tMax is evaluated here (`early` = none of the reference's early-outs fired and
@@ -95,22 +117,22 @@ DEV bool slab_partial(float mnx, float mny, float mnz, float mxx, float mxy, flo
     return !(out1 | out2) & (tMax > 0.0f);
 }
 
-// shapes.cpp:172-273
-DEV bool triangle_test(const RayState &r, float tMax, V3 p0, V3 p1, V3 p2, float &b0, float &b1,
-                       float &b2, float &tHit) {
-    if (len2(cross(sub(p2, p0), sub(p1, p0))) == 0.0f) return false;
+// shapes.cpp:172-273.  `degenerate` is the reference's first test
+// (LengthSquared(Cross(p2 - p0, p1 - p0)) == 0, :176-177): it depends on the triangle only and
+// is evaluated once, with the same float32 operations, when the scene is baked (kPrimDegenerate).
+DEV bool triangle_test(const RayState &r, float tMax, bool degenerate, V3 p0, V3 p1, V3 p2,
+                       float &b0, float &b1, float &b2, float &tHit) {
+    if (degenerate) return false;
     V3 a = sub(p0, r.o), b = sub(p1, r.o), c = sub(p2, r.o);
-    float ax = __builtin_fabsf(r.d.x), ay = __builtin_fabsf(r.d.y), az = __builtin_fabsf(r.d.z);
-    int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+    const int kz = r.kz;
     int kx = kz + 1;
     if (kx == 3) kx = 0;
     int ky = kx + 1;
     if (ky == 3) ky = 0;
-    float dx = sel3(r.d, kx), dy = sel3(r.d, ky), dz = sel3(r.d, kz);
     float p0x = sel3(a, kx), p0y = sel3(a, ky), p0z = sel3(a, kz);
     float p1x = sel3(b, kx), p1y = sel3(b, ky), p1z = sel3(b, kz);
     float p2x = sel3(c, kx), p2y = sel3(c, ky), p2z = sel3(c, kz);
-    float sx = -dx / dz, sy = -dy / dz, sz = 1.0f / dz;
+    const float sx = r.sx, sy = r.sy, sz = r.sz;
     p0x += sx * p0z;
     p0y += sy * p0z;
     p1x += sx * p1z;
@@ -194,31 +216,31 @@ DEV V3 lerp3(float t, V3 a, V3 b) {  // (1 - t) * a + t * b, util/vecmath.h:410-
     return {omt * a.x + t * b.x, omt * a.y + t * b.y, omt * a.z + t * b.z};
 }
 
-DEV void patch_root(float u, const RayState &r, V3 p00, V3 p10, V3 p01, V3 p11, float &vnum,
+DEV void patch_root(float u, const RayState &r, V3 rd, V3 p00, V3 p10, V3 p01, V3 p11, float &vnum,
                     float &tnum, float &p2) {
     V3 uo = lerp3(u, p00, p10);
     V3 ud = sub(lerp3(u, p01, p11), uo);
     V3 deltao = sub(uo, r.o);
-    V3 perp = cross(r.d, ud);
+    V3 perp = cross(rd, ud);
     p2 = len2(perp);
-    vnum = det3({deltao.x, r.d.x, perp.x}, {deltao.y, r.d.y, perp.y}, {deltao.z, r.d.z, perp.z});
+    vnum = det3({deltao.x, rd.x, perp.x}, {deltao.y, rd.y, perp.y}, {deltao.z, rd.z, perp.z});
     tnum = det3({deltao.x, ud.x, perp.x}, {deltao.y, ud.y, perp.y}, {deltao.z, ud.z, perp.z});
 }
 
 // shapes.h:1279-1347
-DEV bool patch_test(const RayState &r, float tMax, V3 p00, V3 p10, V3 p01, V3 p11, float &uOut,
+DEV bool patch_test(const RayState &r, V3 rd, float tMax, V3 p00, V3 p10, V3 p01, V3 p11, float &uOut,
                     float &vOut, float &tOut) {
-    float a = dot(cross(sub(p10, p00), sub(p01, p11)), r.d);
-    float c = dot(cross(sub(p00, r.o), r.d), sub(p01, p00));
-    float b = dot(cross(sub(p10, r.o), r.d), sub(p11, p10)) - (a + c);
+    float a = dot(cross(sub(p10, p00), sub(p01, p11)), rd);
+    float c = dot(cross(sub(p00, r.o), rd), sub(p01, p00));
+    float b = dot(cross(sub(p10, r.o), rd), sub(p11, p10)) - (a + c);
     float u1, u2;
     if (!quadratic(a, b, c, u1, u2)) return false;
-    float eps = gamma_f(10) * (maxabs(r.o) + maxabs(r.d) + maxabs(p00) + maxabs(p10) +
+    float eps = gamma_f(10) * (maxabs(r.o) + maxabs(rd) + maxabs(p00) + maxabs(p10) +
                                maxabs(p01) + maxabs(p11));
     float t = tMax, u = 0.0f, v = 0.0f;
     if (0 <= u1 && u1 <= 1) {
         float v1, t1, p2;
-        patch_root(u1, r, p00, p10, p01, p11, v1, t1, p2);
+        patch_root(u1, r, rd, p00, p10, p01, p11, v1, t1, p2);
         if (t1 > p2 * eps && 0 <= v1 && v1 <= p2) {
             u = u1;
             v = v1 / p2;
@@ -227,7 +249,7 @@ DEV bool patch_test(const RayState &r, float tMax, V3 p00, V3 p10, V3 p01, V3 p1
     }
     if (0 <= u2 && u2 <= 1 && u2 != u1) {
         float v2, t2, p2;
-        patch_root(u2, r, p00, p10, p01, p11, v2, t2, p2);
+        patch_root(u2, r, rd, p00, p10, p01, p11, v2, t2, p2);
         t2 /= p2;
         if (0 <= v2 && v2 <= p2 && t > t2 && t2 > eps) {
             t = t2;
@@ -261,16 +283,33 @@ constexpr int kDone = (int)0x80000000;  // never a leaf ref: ~slot with slot = 0
 // as soon as their refs are known (speed only; compile-time so that the wait for the step's
 // own record loads does not have to cover the prefetches).  PF = 2: only once the queues are
 // exhausted, i.e. while the launch drains and each remaining ray is a bare latency chain.
+// waves/SIMD the register allocator must leave room for (measured in steady state: closest
+// hit 5 -> 6 waves is +9 %; beyond that the spills cost more than the extra waves hide)
+#ifndef NNBVH_MINW_CLOSEST
+#define NNBVH_MINW_CLOSEST 6
+#endif
+#ifndef NNBVH_MINW_ANY
+#define NNBVH_MINW_ANY 6
+#endif
 template <int MODE, int W, int PF>
-__global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
+__global__ __launch_bounds__(kBlockThreads, (MODE == 0 ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY))
+void trace_kernel(TraceParams p) {
     __shared__ int s_ref[kBlockThreads / 64][W][64];
     __shared__ float s_key[kBlockThreads / 64][W][64];
+    // Cold per-ray state parked in LDS ([field][lane], conflict-free) instead of VGPRs: the
+    // ray index (read when the ray retires), the direction (read by the patch test only; the
+    // triangle test uses the precomputed shear) and, closest hit, the current best hit
+    // (written on an accepted hit, read at retire).  Frees 4 / 8 registers per lane.
+    constexpr int kColdRi = 0, kColdD = 1, kColdHit = 4, kColdFields = (MODE == 0) ? 8 : 4;
+    __shared__ float s_cold[kBlockThreads / 64][kColdFields][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int gtid = blockIdx.x * kBlockThreads + threadIdx.x;
     int(*sref)[64] = s_ref[wave];
     float(*skey)[64] = s_key[wave];
+    float(*cold)[64] = s_cold[wave];
+    cold[kColdRi][lane] = __int_as_float(-1);  // ray this lane carries, -1 = none
     const long spillStride = (long)gridDim.x * kBlockThreads;
 
     // which queue this wave drains first: its XCD's share of the batch (speed only)
@@ -286,10 +325,9 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
     unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // trips/lanes per kind (I, P, R); [6..8] = sum nInt,nPrim,nIdle over I trips
 #endif
     RayState r;
-    float tMax = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
-    int hitPrim = -1, visited = 0, tests = 0;
+    float tMax = 0.0f;
+    int visited = 0, tests = 0;
     int cur = kDone, sp = 0, base = 0;
-    int ri = -1;         // ray this lane carries, -1 = none (n < 2^31 is enforced by the ABI)
     bool found = false;  // MODE 1/2
     bool exhausted = false;
     unsigned pf0 = 0, pf1 = 0;  // landing registers of the child-record prefetches
@@ -344,14 +382,15 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
 #endif
         if (nIdle == 64 || (sR > sI && sR > sP)) {
             // ---- retire finished rays, refill idle lanes -------------------------------
-            if (isIdle && ri >= 0) {
+            const int ri = isIdle ? __float_as_int(cold[kColdRi][lane]) : -1;
+            if (ri >= 0) {
                 if (MODE == 0) {
                     float4 h0, h1;
-                    h0.x = __int_as_float(hitPrim);
+                    h0.x = cold[kColdHit][lane];  // hit primitive id (bit pattern)
                     h0.y = tMax;
-                    h0.z = hb0;
-                    h0.w = hb1;
-                    h1.x = hb2;
+                    h0.z = cold[kColdHit + 1][lane];
+                    h0.w = cold[kColdHit + 2][lane];
+                    h1.x = cold[kColdHit + 3][lane];
                     h1.y = __int_as_float(visited);
                     h1.z = __int_as_float(tests);
                     h1.w = 0.0f;
@@ -365,8 +404,8 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                         if (p.testsOut) p.testsOut[ri] = tests;
                     }
                 }
-                ri = -1;
             }
+            int newRi = -1;  // n < 2^31 is enforced by the ABI
             if (exhausted) break;  // only reached with every lane idle (sR == 0 otherwise)
             long start = 0;
             for (;;) {  // find a queue with work left (own XCD's first, then steal)
@@ -379,7 +418,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                     const int rank = __builtin_amdgcn_mbcnt_hi(
                         (unsigned)(idleMask >> 32),
                         __builtin_amdgcn_mbcnt_lo((unsigned)idleMask, 0u));
-                    if (isIdle && start + rank < qEnd) ri = (int)(start + rank);
+                    if (isIdle && start + rank < qEnd) newRi = (int)(start + rank);
                     break;
                 }
                 if (++queuesTried >= p.nQueues) {
@@ -388,16 +427,25 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                 }
                 q = (q + 1 == p.nQueues) ? 0 : q + 1;
             }
-            if (ri >= 0 && isIdle) {
-                const float4 *in = reinterpret_cast<const float4 *>(p.rays) + 2 * (long)ri;
+            if (isIdle) cold[kColdRi][lane] = __int_as_float(newRi);
+            if (newRi >= 0) {
+                const float4 *in = reinterpret_cast<const float4 *>(p.rays) + 2 * (long)newRi;
                 const float4 r0 = in[0], r1 = in[1];
                 r.o = {r0.x, r0.y, r0.z};
                 tMax = r0.w;
-                r.d = {r1.x, r1.y, r1.z};
+                const V3 d = {r1.x, r1.y, r1.z};
+                cold[kColdD][lane] = d.x;
+                cold[kColdD + 1][lane] = d.y;
+                cold[kColdD + 2][lane] = d.z;
                 // aggregates.cpp:534-535
-                r.inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
-                hitPrim = -1;
-                hb0 = hb1 = hb2 = 0.0f;
+                r.inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+                ray_shear(r, d);
+                if (MODE == 0) {
+                    cold[kColdHit][lane] = __int_as_float(-1);
+                    cold[kColdHit + 1][lane] = 0.0f;
+                    cold[kColdHit + 2][lane] = 0.0f;
+                    cold[kColdHit + 3][lane] = 0.0f;
+                }
                 visited = 1;  // the root
                 tests = 0;
                 found = false;
@@ -423,22 +471,23 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                 float x0, x1, x2, th;
                 int next;
                 if (!(flags & kPrimPatch)) {
-                    hit = triangle_test(r, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                        {s2.x, s2.y, s2.z}, x0, x1, x2, th);
+                    hit = triangle_test(r, tMax, (flags & kPrimDegenerate) != 0, {s0.x, s0.y, s0.z},
+                                        {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z}, x0, x1, x2, th);
                     next = slot + 3;
                 } else {
                     const float4 s3 = p.prims[slot + 3];
                     x2 = 0.0f;
-                    hit = patch_test(r, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                    const V3 rd = {cold[kColdD][lane], cold[kColdD + 1][lane], cold[kColdD + 2][lane]};
+                    hit = patch_test(r, rd, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
                                      {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
                     next = slot + 4;
                 }
                 if (hit) {
                     if (MODE == 0) {
-                        hitPrim = __float_as_int(s0.w);
-                        hb0 = x0;
-                        hb1 = x1;
-                        hb2 = x2;
+                        cold[kColdHit][lane] = s0.w;  // primitive id bits
+                        cold[kColdHit + 1][lane] = x0;
+                        cold[kColdHit + 2][lane] = x1;
+                        cold[kColdHit + 3][lane] = x2;
                         tMax = th;
                     } else {
                         found = true;
@@ -480,7 +529,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(TraceParams p) {
                 const bool e0 = slab_partial(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, t0);
                 const bool e1 = slab_partial(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, t1);
                 const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
-                const bool nearE = swap ? e1 : e0, farE = swap ? e0 : e1;
+                const bool nearE = (swap & e1) | (!swap & e0), farE = (swap & e0) | (!swap & e1);
                 const float nearT = swap ? t1 : t0, farT = swap ? t0 : t1;
                 visited += 1;  // the near child is entered now
                 if (MODE == 1 || farE) {

@@ -30,9 +30,11 @@ static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 // Prim stream: 16-B slots, primitives in the reference's leaf order.
 //   triangle (3 slots): {p0.xyz, id} {p1.xyz, flags} {p2.xyz, 0}
 //   patch    (4 slots): {p00.xyz, id} {p10.xyz, flags} {p01.xyz, 0} {p11.xyz, 0}
-// flags bit0 = last primitive of its leaf, bit1 = bilinear patch.
+// flags bit0 = last primitive of its leaf, bit1 = bilinear patch, bit2 = degenerate triangle
+// (LengthSquared(Cross(p2 - p0, p1 - p0)) == 0, shapes.cpp:176-177, evaluated at bake time).
 constexpr uint32_t kPrimLast = 1u;
 constexpr uint32_t kPrimPatch = 2u;
+constexpr uint32_t kPrimDegenerate = 4u;
 
 constexpr int kMaxStack = 64;  // the reference's nodesToVisit[64], aggregates.cpp:538
 
