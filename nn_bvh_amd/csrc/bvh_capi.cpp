@@ -70,6 +70,7 @@ struct nnbvh_scene {
     int refill_weight = 8;
     unsigned long long *d_stats = nullptr;  // diagnostics (NNBVH_STATS builds)
     int prefetch = 0;
+    int int_repeat = 3;
     int max_grid_threads = 0;
     std::mutex mu;
     std::map<hipStream_t, Workspace> workspaces;
@@ -394,6 +395,12 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
             return NNBVH_ERR_ARG;
         }
         s->blocks_per_cu = value;
+    } else if (k == "int_repeat") {
+        if (value < 1 || value > 16) {
+            set_error("set_option: int_repeat must be 1..16");
+            return NNBVH_ERR_ARG;
+        }
+        s->int_repeat = value;
     } else if (k == "prefetch") {
         if (value < 0 || value > 2) {
             set_error("set_option: prefetch must be 0, 1 or 2");
@@ -459,6 +466,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     p.primWeight = s->prim_weight;
     p.refillWeight = s->refill_weight;
     p.stats = s->d_stats;
+    p.intRepeat = s->int_repeat;
     p.spill = w->spill;
     if (!hip_ok(hipMemsetAsync(w->queue, 0, kMaxQueues * kQueueStrideWords * sizeof(unsigned),
                                stream),

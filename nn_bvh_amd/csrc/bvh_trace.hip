@@ -498,8 +498,11 @@ void trace_kernel(TraceParams p) {
                 else cur = ~next;
             }
         } else {
-            // ---- interior step ------------------------------------------------------------
-            if (isInt) {
+            // ---- interior step(s): up to p.intRepeat in a row before the next scheduling
+            // decision (lanes that leave the interior state sit the remaining ones out) -------
+            for (int rep = 0; rep < p.intRepeat; ++rep) {
+            if (rep > 0 && __ballot(cur >= 0) == 0ull) break;
+            if (cur >= 0) {
                 // "use" of the words the previous interior step's prefetch loads returned: this
                 // is what keeps those loads alive in the compiled code (the values themselves
                 // are irrelevant); they landed long ago, so the wait emitted here is free
@@ -549,6 +552,7 @@ void trace_kernel(TraceParams p) {
                 }
                 if (nearE && nearT < tMax) cur = nearRef;
                 else cur = pop_next();
+            }
             }
         }
     }
