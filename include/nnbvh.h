@@ -120,6 +120,27 @@ int nnbvh_intersect_closest_device(nnbvh_scene *s, const void *d_rays, int64_t n
 int nnbvh_intersect_any_device(nnbvh_scene *s, const void *d_rays, int64_t n, void *d_occluded,
                                void *d_nodes_visited, void *d_prim_tests, void *stream);
 
+/* ---- several independent batches at once --------------------------------------------------
+ * One call traces n_batches independent ray batches (e.g. the closest-hit queue and the
+ * shadow-ray queue of one wavefront iteration: wavefront/integrator.cpp:403-406 and :575-579
+ * are independent of each other).  The batches run concurrently on internal streams that are
+ * forked from and joined back into `stream`, so to the caller the call is ONE asynchronous
+ * operation on `stream`; a launch's tail (the dependent chain of its longest ray) then
+ * overlaps the other batches' work instead of idling the GPU. */
+#define NNBVH_BATCH_CLOSEST 0
+#define NNBVH_BATCH_ANY 1
+typedef struct nnbvh_batch {
+    int32_t kind; /* NNBVH_BATCH_CLOSEST: d_out = nnbvh_hit[n]; NNBVH_BATCH_ANY: d_out = uint8[n] */
+    int32_t pad;
+    const void *d_rays;    /* nnbvh_ray[n], device */
+    int64_t n;
+    void *d_out;
+    void *d_nodes_visited; /* ANY only, optional int32[n] (exact counts) */
+    void *d_prim_tests;    /* ANY only, optional int32[n] */
+} nnbvh_batch;
+int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n_batches,
+                               void *stream);
+
 /* tuning knobs (speed only, never results): "stack_window" (LDS entries per lane: 4, 8, 16),
  * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "prim_weight" / "refill_weight" (1..64:
  * how much a lane waiting on a primitive test / an idle lane counts against a lane waiting on

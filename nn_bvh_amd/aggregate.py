@@ -163,6 +163,18 @@ class BVHAggregate:
         check(_lib.lib().nnbvh_intersect_closest_device(self._h, d_rays, n, d_hits, stream),
               "nnbvh_intersect_closest_device")
 
+    def trace_batches_device(self, batches, stream=0):
+        """batches: iterable of (kind, d_rays, n, d_out[, d_nodes_visited, d_prim_tests]) with kind
+        "closest" or "any"; all traced concurrently, ordered as one operation on `stream`."""
+        arr = np.zeros(len(batches), _lib.BATCH_DTYPE)
+        for i, b in enumerate(batches):
+            arr[i]["kind"] = {"closest": 0, "any": 1}[b[0]]
+            arr[i]["d_rays"], arr[i]["n"], arr[i]["d_out"] = b[1], b[2], b[3]
+            if len(b) > 4:
+                arr[i]["d_nodes_visited"], arr[i]["d_prim_tests"] = b[4] or 0, b[5] or 0
+        check(_lib.lib().nnbvh_trace_batches_device(self._h, ptr(arr), len(arr), stream),
+              "nnbvh_trace_batches_device")
+
     def intersect_p_device(self, d_rays, d_occ, n, d_visited=None, d_tests=None, stream=0):
         check(_lib.lib().nnbvh_intersect_any_device(self._h, d_rays, n, d_occ, d_visited, d_tests,
                                                     stream), "nnbvh_intersect_any_device")

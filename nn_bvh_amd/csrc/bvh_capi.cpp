@@ -74,6 +74,11 @@ struct nnbvh_scene {
     int max_grid_threads = 0;
     std::mutex mu;
     std::map<hipStream_t, Workspace> workspaces;
+    // fork/join machinery of nnbvh_trace_batches_device
+    static constexpr int kSideStreams = 4;
+    hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 // -------------------------------------------------------------------------------------
@@ -313,6 +318,11 @@ void nnbvh_scene_destroy(nnbvh_scene *s) {
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
     }
+    for (int k = 0; k < nnbvh_scene::kSideStreams; ++k) {
+        if (s->side[k]) (void)hipStreamDestroy(s->side[k]);
+        if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]);
+    }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     (void)hipFree(s->d_wide);
     (void)hipFree(s->d_prims);
     if (s->d_stats) (void)hipFree(s->d_stats);
@@ -532,6 +542,62 @@ int nnbvh_intersect_any_device(nnbvh_scene *s, const void *d_rays, int64_t n, vo
     const int mode = (d_nodes_visited || d_prim_tests) ? 1 : 2;
     return launch(s, mode, d_rays, n, nullptr, d_occluded, d_nodes_visited, d_prim_tests,
                   (hipStream_t)stream, w);
+}
+
+int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n_batches,
+                               void *stream_) {
+    if (!s || n_batches < 0 || (n_batches > 0 && !batches)) {
+        set_error("trace_batches_device: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    for (int i = 0; i < n_batches; ++i) {
+        const nnbvh_batch &b = batches[i];
+        if ((b.kind != NNBVH_BATCH_CLOSEST && b.kind != NNBVH_BATCH_ANY) || b.n < 0 ||
+            b.n >= 0x7fffffffLL || (b.n > 0 && (!b.d_rays || !b.d_out))) {
+            set_error("trace_batches_device: bad batch (kind, size or null buffer)");
+            return NNBVH_ERR_ARG;
+        }
+    }
+    if (n_batches == 0) return NNBVH_OK;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(s->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!s->ev_fork) {
+        bool ok = hip_ok(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming), "hipEventCreate");
+        for (int k = 0; ok && k < nnbvh_scene::kSideStreams; ++k)
+            ok = hip_ok(hipStreamCreateWithFlags(&s->side[k], hipStreamNonBlocking), "hipStreamCreate") &&
+                 hip_ok(hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming), "hipEventCreate");
+        if (!ok) return NNBVH_ERR_DEVICE;
+    }
+    if (!hip_ok(hipEventRecord(s->ev_fork, stream), "hipEventRecord(fork)")) return NNBVH_ERR_DEVICE;
+    bool used[nnbvh_scene::kSideStreams] = {false, false, false, false};
+    for (int i = 0; i < n_batches; ++i) {
+        const nnbvh_batch &b = batches[i];
+        if (b.n == 0) continue;
+        const int k = i % nnbvh_scene::kSideStreams;
+        if (!used[k]) {
+            if (!hip_ok(hipStreamWaitEvent(s->side[k], s->ev_fork, 0), "hipStreamWaitEvent(fork)"))
+                return NNBVH_ERR_DEVICE;
+            used[k] = true;
+        }
+        Workspace *w = workspace_for(s, s->side[k]);
+        if (!w) return NNBVH_ERR_DEVICE;
+        int rc;
+        if (b.kind == NNBVH_BATCH_CLOSEST)
+            rc = launch(s, 0, b.d_rays, b.n, b.d_out, nullptr, nullptr, nullptr, s->side[k], w);
+        else
+            rc = launch(s, (b.d_nodes_visited || b.d_prim_tests) ? 1 : 2, b.d_rays, b.n, nullptr,
+                        b.d_out, b.d_nodes_visited, b.d_prim_tests, s->side[k], w);
+        if (rc != NNBVH_OK) return rc;
+    }
+    for (int k = 0; k < nnbvh_scene::kSideStreams; ++k) {
+        if (!used[k]) continue;
+        if (!hip_ok(hipEventRecord(s->ev_join[k], s->side[k]), "hipEventRecord(join)") ||
+            !hip_ok(hipStreamWaitEvent(stream, s->ev_join[k], 0), "hipStreamWaitEvent(join)"))
+            return NNBVH_ERR_DEVICE;
+    }
+    return NNBVH_OK;
 }
 
 int nnbvh_intersect_closest(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits) {

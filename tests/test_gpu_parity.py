@@ -203,3 +203,41 @@ def test_reference_scene_blobs_full_size(name):
     again["tmax"][m] = hits["t"][m] * np.float32(0.9999)  # just short of the closest hit: miss
     assert (agg.Intersect(again)["prim"][m] == -1).all()
     agg.close()
+
+
+def test_trace_batches_equals_separate_calls():
+    """nnbvh_trace_batches_device (closest + any + any-with-counts traced concurrently on
+    internal streams) must give exactly what the separate entry points give."""
+    import torch
+    from nn_bvh_amd import HIT_DTYPE
+    verts, prims = ss.random_soup(5000, 300, 31)
+    agg = BVHAggregate(prims, verts)
+    ra = scene.random_rays(30000, verts.min(0), verts.max(0), 1)
+    rb = scene.random_rays(20000, verts.min(0), verts.max(0), 2, tmax=np.float32(1 - 1e-4))
+    exp_a = agg.Intersect(ra)
+    exp_b, exp_v, exp_t = agg.IntersectP(rb, counts=True)
+
+    def dev(a):
+        return torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda()
+    da, db = dev(ra), dev(rb)
+    oa = torch.zeros(len(ra) * 32, dtype=torch.uint8, device="cuda")
+    ob1 = torch.zeros(len(rb), dtype=torch.uint8, device="cuda")
+    ob2 = torch.zeros(len(rb), dtype=torch.uint8, device="cuda")
+    ov = torch.zeros(len(rb), dtype=torch.int32, device="cuda")
+    ot = torch.zeros(len(rb), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):  # repeated use re-records the fork/join events
+        agg.trace_batches_device([("closest", da.data_ptr(), len(ra), oa.data_ptr()),
+                                  ("any", db.data_ptr(), len(rb), ob1.data_ptr()),
+                                  ("any", db.data_ptr(), len(rb), ob2.data_ptr(), ov.data_ptr(),
+                                   ot.data_ptr()),
+                                  ("closest", da.data_ptr(), 0, oa.data_ptr())], st)
+    torch.cuda.synchronize()
+    assert oa.cpu().numpy().view(HIT_DTYPE).tobytes() == exp_a.tobytes()
+    assert (ob1.cpu().numpy() == exp_b).all() and (ob2.cpu().numpy() == exp_b).all()
+    assert (ov.cpu().numpy() == exp_v).all() and (ot.cpu().numpy() == exp_t).all()
+    agg.trace_batches_device([], st)
+    from nn_bvh_amd import NNBVHError
+    with pytest.raises(NNBVHError, match="bad batch"):
+        agg.trace_batches_device([("closest", 0, 5, oa.data_ptr())], st)
+    agg.close()
