@@ -241,3 +241,41 @@ def test_trace_batches_equals_separate_calls():
     with pytest.raises(NNBVHError, match="bad batch"):
         agg.trace_batches_device([("closest", 0, 5, oa.data_ptr())], st)
     agg.close()
+
+
+def test_concurrent_host_threads_and_streams():
+    """The ABI's thread-safety contract: concurrent calls from several host threads on one
+    scene, and concurrent device-pointer launches on several streams, give each call exactly
+    its own serial result."""
+    import threading
+    import torch
+    from nn_bvh_amd import HIT_DTYPE
+    verts, prims = ss.random_soup(6000, 0, 41)
+    agg = BVHAggregate(prims, verts)
+    batches = [scene.random_rays(15000 + 1000 * k, verts.min(0), verts.max(0), 100 + k) for k in range(6)]
+    expected = [agg.Intersect(b) for b in batches]
+    got = [None] * len(batches)
+
+    def work(k):
+        for _ in range(3):
+            got[k] = agg.Intersect(batches[k])
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(batches))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(len(batches)):
+        assert got[k].tobytes() == expected[k].tobytes(), f"thread {k}"
+    # device path: one stream per batch, all in flight together
+    streams = [torch.cuda.Stream() for _ in batches]
+    d_in = [torch.from_numpy(b.view(np.uint8).reshape(-1).copy()).cuda() for b in batches]
+    d_out = [torch.zeros(len(b) * 32, dtype=torch.uint8, device="cuda") for b in batches]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k, st in enumerate(streams):
+            agg.intersect_device(d_in[k].data_ptr(), d_out[k].data_ptr(), len(batches[k]), st.cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(len(batches)):
+        assert d_out[k].cpu().numpy().view(HIT_DTYPE).tobytes() == expected[k].tobytes(), f"stream {k}"
+    agg.close()
