@@ -49,6 +49,8 @@ typedef struct nnbvh_linear_node {
 
 #define NNBVH_PRIM_TRIANGLE 0       /* Triangle      (shapes.h:833-1192) */
 #define NNBVH_PRIM_BILINEAR_PATCH 1 /* BilinearPatch (shapes.h:1350-1539): v = p00,p10,p01,p11 */
+#define NNBVH_PRIM_INSTANCE 2       /* TransformedPrimitive (cpu/primitive.h:83-101): v[0] = index
+                                       into the instance table; top-level tree only */
 
 /* One entry of BVHAggregate::primitives: the shape handle flattened to global vertex
  * indices (Triangle{meshIndex,triIndex} -> mesh->vertexIndices[3*tri..], shapes.cpp:326-328). */
@@ -76,8 +78,22 @@ typedef struct nnbvh_hit {
     float b0, b1, b2; /* triangle barycentrics; patch: b0 = u, b1 = v, b2 = 0 */
     int32_t nodes_visited;
     int32_t prim_tests;
-    int32_t pad;
+    int32_t instance; /* 0: hit in the top-level tree (or miss); k + 1: inside instance k, and
+                         then `prim` is the child tree's primitive id and t, b* are those of the
+                         instance-space ray, exactly what TransformedPrimitive::Intersect returns */
 } nnbvh_hit;
+
+/* A TransformedPrimitive: a child BVHAggregate (an object instance, scene.cpp:1521-1577) behind
+ * a static transform.  Matrices are the first three rows of pbrt's 4x4 Transform::m / mInv
+ * (row-major; the fourth row of an affine transform is 0 0 0 1).  The child tree occupies
+ * nodes[root, root + n_nodes) of the scene's node array, in the same DFS layout; its leaves
+ * index the scene's primitive table.  Several instances may share one child tree. */
+typedef struct nnbvh_instance {
+    float render_from_prim[12];
+    float prim_from_render[12];
+    int32_t root;
+    int32_t n_nodes;
+} nnbvh_instance;
 
 typedef struct nnbvh_scene nnbvh_scene;
 typedef struct nnbvh_build nnbvh_build;
@@ -92,6 +108,12 @@ int nnbvh_device_count(void);
 #define NNBVH_SPLIT_EQUAL_COUNTS 3
 nnbvh_build *nnbvh_build_create(const nnbvh_prim *prims, int n_prims, const float *verts,
                                 int n_verts, int max_prims_in_node, int split_method);
+/* same, for a primitive list that contains NNBVH_PRIM_INSTANCE entries: prim_bounds holds
+ * 6 floats (min, max) per primitive and is read for the instance entries */
+nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims,
+                                            const float *verts, int n_verts,
+                                            const float *prim_bounds, int max_prims_in_node,
+                                            int split_method);
 const nnbvh_linear_node *nnbvh_build_nodes(const nnbvh_build *b, int *n_nodes);
 const nnbvh_prim *nnbvh_build_ordered_prims(const nnbvh_build *b, int *n_prims);
 int nnbvh_build_depth(const nnbvh_build *b); /* edges root -> deepest leaf */
@@ -101,6 +123,18 @@ void nnbvh_build_destroy(nnbvh_build *b);
 nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
                                 const nnbvh_prim *ordered_prims, int n_prims,
                                 const float *verts, int n_verts, int device);
+/* two-level scene: nodes[0, n_top_nodes) is the top-level tree (may contain NNBVH_PRIM_INSTANCE
+ * leaves), the rest are child trees named by `instances`.  Replaces the TransformedPrimitive
+ * path of cpu/primitive.cpp:112-131 (AnimatedPrimitive is not covered). */
+nnbvh_scene *nnbvh_scene_create_instanced(const nnbvh_linear_node *nodes, int n_nodes,
+                                          int n_top_nodes, const nnbvh_prim *ordered_prims,
+                                          int n_prims, const float *verts, int n_verts,
+                                          const nnbvh_instance *instances, int n_instances,
+                                          int device);
+/* Transform::operator()(const Bounds3f&) (util/transform.cpp:134-139): the bounds an instance
+ * primitive presents to the top-level builder (TransformedPrimitive::Bounds, primitive.h:94) */
+void nnbvh_transform_bounds(const float render_from_prim[12], const float in_min_max[6],
+                            float out_min_max[6]);
 void nnbvh_scene_destroy(nnbvh_scene *s);
 int nnbvh_scene_bounds(const nnbvh_scene *s, float out_min_max[6]);
 /* what the baked device layout looks like: [0]=interior records, [1]=prim-stream slots,

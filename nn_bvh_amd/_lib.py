@@ -14,10 +14,12 @@ NODE_DTYPE = np.dtype([("pmin", "<f4", 3), ("pmax", "<f4", 3), ("offset", "<i4")
                        ("nprims", "<u2"), ("axis", "u1"), ("pad", "u1")])
 PRIM_DTYPE = np.dtype([("kind", "<i4"), ("id", "<i4"), ("v", "<i4", 4)])
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("tmax", "<f4"), ("d", "<f4", 3), ("time", "<f4")])
+INSTANCE_DTYPE = np.dtype([("render_from_prim", "<f4", 12), ("prim_from_render", "<f4", 12),
+                           ("root", "<i4"), ("n_nodes", "<i4")])
 BATCH_DTYPE = np.dtype([("kind", "<i4"), ("pad", "<i4"), ("d_rays", "<u8"), ("n", "<i8"),
                         ("d_out", "<u8"), ("d_nodes_visited", "<u8"), ("d_prim_tests", "<u8")])
 HIT_DTYPE = np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"),
-                      ("nodes_visited", "<i4"), ("prim_tests", "<i4"), ("pad", "<i4")])
+                      ("nodes_visited", "<i4"), ("prim_tests", "<i4"), ("instance", "<i4")])
 assert NODE_DTYPE.itemsize == 32 and PRIM_DTYPE.itemsize == 24
 assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 32
 
@@ -27,7 +29,8 @@ EXPORTS = [
     "nnbvh_scene_create", "nnbvh_scene_destroy", "nnbvh_scene_bounds", "nnbvh_scene_info",
     "nnbvh_intersect_closest", "nnbvh_intersect_any", "nnbvh_intersect_closest_device",
     "nnbvh_intersect_any_device", "nnbvh_scene_set_option", "nnbvh_scene_sched_stats",
-    "nnbvh_trace_batches_device",
+    "nnbvh_trace_batches_device", "nnbvh_scene_create_instanced", "nnbvh_transform_bounds",
+    "nnbvh_build_create_with_bounds",
 ]
 
 _lib = None
@@ -78,6 +81,12 @@ def lib():
     L.nnbvh_intersect_any_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.nnbvh_scene_set_option.restype = i32
     L.nnbvh_scene_set_option.argtypes = [vp, ctypes.c_char_p, i32]
+    L.nnbvh_scene_create_instanced.restype = vp
+    L.nnbvh_scene_create_instanced.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32]
+    L.nnbvh_transform_bounds.restype = None
+    L.nnbvh_transform_bounds.argtypes = [vp, vp, vp]
+    L.nnbvh_build_create_with_bounds.restype = vp
+    L.nnbvh_build_create_with_bounds.argtypes = [vp, i32, vp, i32, vp, i32, i32]
     L.nnbvh_trace_batches_device.restype = i32
     L.nnbvh_trace_batches_device.argtypes = [vp, vp, i32, vp]
     L.nnbvh_scene_sched_stats.restype = i32

@@ -50,16 +50,23 @@ class BuiltTree:
         self.depth = depth
 
 
-def build_tree(prims, verts, max_prims_in_node=4, split_method="sah"):
-    """SAH / middle / equal-counts build on the host (no GPU needed)."""
+def build_tree(prims, verts, max_prims_in_node=4, split_method="sah", prim_bounds=None):
+    """SAH / HLBVH / middle / equal-counts build on the host (no GPU needed).  prim_bounds
+    ([n, 6] float32) is required when the list contains instance primitives (kind 2)."""
     L = _lib.lib()
     prims = np.ascontiguousarray(prims, PRIM_DTYPE)
     verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
     if split_method not in SPLIT_METHODS:
         # aggregates.cpp:735-738 warns and falls back to sah; we report instead
         raise NNBVHError(f'BVH split method "{split_method}" unknown')
-    h = L.nnbvh_build_create(ptr(prims), len(prims), ptr(verts), len(verts),
-                             int(max_prims_in_node), SPLIT_METHODS[split_method])
+    if prim_bounds is not None:
+        prim_bounds = np.ascontiguousarray(prim_bounds, np.float32).reshape(len(prims), 6)
+        h = L.nnbvh_build_create_with_bounds(ptr(prims), len(prims), ptr(verts), len(verts),
+                                             ptr(prim_bounds), int(max_prims_in_node),
+                                             SPLIT_METHODS[split_method])
+    else:
+        h = L.nnbvh_build_create(ptr(prims), len(prims), ptr(verts), len(verts),
+                                 int(max_prims_in_node), SPLIT_METHODS[split_method])
     if not h:
         raise NNBVHError("nnbvh_build_create: " + _lib.last_error())
     try:
@@ -86,20 +93,29 @@ class BVHAggregate:
         self._init(tree.nodes, tree.ordered_prims, verts, device, tree.depth)
 
     @classmethod
-    def from_tree(cls, nodes, ordered_prims, verts, device=0):
+    def from_tree(cls, nodes, ordered_prims, verts, device=0, instances=None, n_top_nodes=None):
+        """instances (INSTANCE_DTYPE) + n_top_nodes make a two-level scene: nodes[:n_top_nodes] is
+        the top-level tree, the child trees follow (see nn_bvh_amd.instancing)."""
         self = cls.__new__(cls)
-        self._init(nodes, ordered_prims, verts, device, None)
+        self._init(nodes, ordered_prims, verts, device, None, instances, n_top_nodes)
         return self
 
-    def _init(self, nodes, ordered_prims, verts, device, depth):
+    def _init(self, nodes, ordered_prims, verts, device, depth, instances=None, n_top_nodes=None):
         L = _lib.lib()
         self.nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
         self.ordered_prims = np.ascontiguousarray(ordered_prims, PRIM_DTYPE)
         self.verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         self.device = int(device)
-        self._h = L.nnbvh_scene_create(ptr(self.nodes), len(self.nodes), ptr(self.ordered_prims),
-                                       len(self.ordered_prims), ptr(self.verts), len(self.verts),
-                                       self.device)
+        if instances is not None and len(instances):
+            self.instances = np.ascontiguousarray(instances, _lib.INSTANCE_DTYPE)
+            self._h = L.nnbvh_scene_create_instanced(
+                ptr(self.nodes), len(self.nodes), int(n_top_nodes), ptr(self.ordered_prims),
+                len(self.ordered_prims), ptr(self.verts), len(self.verts), ptr(self.instances),
+                len(self.instances), self.device)
+        else:
+            self._h = L.nnbvh_scene_create(ptr(self.nodes), len(self.nodes), ptr(self.ordered_prims),
+                                           len(self.ordered_prims), ptr(self.verts), len(self.verts),
+                                           self.device)
         if not self._h:
             raise NNBVHError("nnbvh_scene_create: " + _lib.last_error())
         info = np.zeros(6, np.int64)

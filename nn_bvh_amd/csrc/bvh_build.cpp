@@ -427,6 +427,14 @@ extern "C" {
 
 nnbvh_build *nnbvh_build_create(const nnbvh_prim *prims, int n_prims, const float *verts,
                                 int n_verts, int max_prims_in_node, int split_method) {
+    return nnbvh_build_create_with_bounds(prims, n_prims, verts, n_verts, nullptr, max_prims_in_node,
+                                          split_method);
+}
+
+nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims,
+                                            const float *verts, int n_verts,
+                                            const float *prim_bounds, int max_prims_in_node,
+                                            int split_method) {
     if (!prims || !verts || n_prims <= 0 || n_verts <= 0) {
         nnbvh::set_error("nnbvh_build_create: empty primitive or vertex array");
         return nullptr;
@@ -440,11 +448,21 @@ nnbvh_build *nnbvh_build_create(const nnbvh_prim *prims, int n_prims, const floa
     for (int i = 0; i < n_prims; ++i) {
         const nnbvh_prim &p = prims[i];
         int nv = p.kind == NNBVH_PRIM_TRIANGLE ? 3 : p.kind == NNBVH_PRIM_BILINEAR_PATCH ? 4 : 0;
+        bp[i].index = (size_t)i;
+        if (p.kind == NNBVH_PRIM_INSTANCE) {
+            // TransformedPrimitive::Bounds() = renderFromPrimitive(child bounds), supplied
+            if (!prim_bounds) {
+                nnbvh::set_error("nnbvh_build_create: instance primitives need prim_bounds");
+                return nullptr;
+            }
+            bp[i].bounds.add(prim_bounds + 6 * (size_t)i);
+            bp[i].bounds.add(prim_bounds + 6 * (size_t)i + 3);
+            continue;
+        }
         if (!nv) {
             nnbvh::set_error("nnbvh_build_create: unknown primitive kind");
             return nullptr;
         }
-        bp[i].index = (size_t)i;
         for (int k = 0; k < nv; ++k) {
             if (p.v[k] < 0 || p.v[k] >= n_verts) {
                 nnbvh::set_error("nnbvh_build_create: vertex index out of range");

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <string>
@@ -70,6 +71,7 @@ struct nnbvh_scene {
     int refill_weight = 8;
     unsigned long long *d_stats = nullptr;  // diagnostics (NNBVH_STATS builds)
     int prefetch = 0;
+    int instanced = 0;      // two-level scene: use the INST kernels
     int int_repeat = 3;
     int max_grid_threads = 0;
     std::mutex mu;
@@ -84,20 +86,22 @@ struct nnbvh_scene {
 // -------------------------------------------------------------------------------------
 // Tree validation: everything the kernels index with is range-checked here once, so a
 // malformed tree is an NNBVH_ERR_ARG at create time, never a device fault.
-static bool validate_tree(const nnbvh_linear_node *nodes, int n_nodes, int n_prims,
+// Validates the DFS-laid-out tree occupying nodes[root, root + n_tree).  `covered` / `leaf_last`
+// are shared by all trees of a scene (top level + instanced children).
+static bool validate_tree(const nnbvh_linear_node *nodes, int root, int n_tree, const nnbvh_prim *prims,
+                          int n_prims, bool allow_instances, std::vector<uint8_t> &covered,
                           std::vector<uint8_t> &leaf_last, int *depth_out) {
-    if (n_nodes < 1) {
+    if (n_tree < 1) {
         set_error("scene_create: tree has no nodes");
         return false;
     }
-    std::vector<uint8_t> covered((size_t)n_prims, 0);
-    leaf_last.assign((size_t)n_prims, 0);
+    const int n_nodes = root + n_tree;
     // iterative DFS; each frame = (node, end bound of its subtree range, depth)
     struct Frame {
         int node, end, depth;
     };
     std::vector<Frame> st;
-    st.push_back({0, n_nodes, 0});
+    st.push_back({root, n_nodes, 0});
     int visited = 0, max_depth = 0;
     while (!st.empty()) {
         Frame f = st.back();
@@ -124,6 +128,10 @@ static bool validate_tree(const nnbvh_linear_node *nodes, int n_nodes, int n_pri
                     return false;
                 }
                 covered[(size_t)nd.offset + i] = 1;
+                if (!allow_instances && prims[(size_t)nd.offset + i].kind == NNBVH_PRIM_INSTANCE) {
+                    set_error("scene_create: nested instances are not supported");
+                    return false;
+                }
             }
             leaf_last[(size_t)nd.offset + nd.nprims - 1] = 1;
         } else {
@@ -140,7 +148,7 @@ static bool validate_tree(const nnbvh_linear_node *nodes, int n_nodes, int n_pri
             st.push_back({c0, c1, f.depth + 1});
         }
     }
-    if (visited != n_nodes) {
+    if (visited != n_tree) {
         set_error("scene_create: unreachable nodes in the array");
         return false;
     }
@@ -183,16 +191,37 @@ int nnbvh_device_count(void) {
     return n;
 }
 
-nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
-                                const nnbvh_prim *prims, int n_prims, const float *verts,
-                                int n_verts, int device) {
-    if (!nodes || !prims || !verts || n_prims <= 0 || n_verts <= 0) {
+static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, int n_top_nodes,
+                                 const nnbvh_prim *prims, int n_prims, const float *verts,
+                                 int n_verts, const nnbvh_instance *instances, int n_instances,
+                                 int device) {
+    if (!nodes || !prims || !verts || n_prims <= 0 || n_verts <= 0 || n_instances < 0 ||
+        (n_instances > 0 && !instances) || n_top_nodes < 1 || n_top_nodes > n_nodes) {
         set_error("scene_create: null or empty input array");
         return nullptr;
     }
-    std::vector<uint8_t> leaf_last;
+    std::vector<uint8_t> leaf_last((size_t)n_prims, 0), covered((size_t)n_prims, 0);
     int depth = 0;
-    if (!validate_tree(nodes, n_nodes, n_prims, leaf_last, &depth)) return nullptr;
+    if (!validate_tree(nodes, 0, n_top_nodes, prims, n_prims, n_instances > 0, covered, leaf_last,
+                       &depth))
+        return nullptr;
+    // instanced children: trees in nodes[n_top_nodes, n_nodes); several instances may share one
+    int child_depth = 0;
+    std::vector<uint8_t> tree_seen((size_t)n_nodes, 0);
+    for (int k = 0; k < n_instances; ++k) {
+        const nnbvh_instance &in = instances[k];
+        if (in.root < n_top_nodes || in.n_nodes < 1 || (int64_t)in.root + in.n_nodes > n_nodes) {
+            set_error("scene_create: instance child tree outside the node array");
+            return nullptr;
+        }
+        if (tree_seen[(size_t)in.root]) continue;
+        tree_seen[(size_t)in.root] = 1;
+        int d = 0;
+        if (!validate_tree(nodes, in.root, in.n_nodes, prims, n_prims, false, covered, leaf_last, &d))
+            return nullptr;
+        child_depth = std::max(child_depth, d + 1);
+    }
+    depth += child_depth;  // pending entries of the outer walk + those of the child walk
     if (depth > kMaxStack) {
         // the reference's nodesToVisit[64] (aggregates.cpp:538) would overflow silently
         set_error("scene_create: tree deeper than the 64-entry traversal stack");
@@ -202,10 +231,17 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
     std::vector<int64_t> slot_of((size_t)n_prims + 1, 0);
     for (int k = 0; k < n_prims; ++k) {
         const nnbvh_prim &p = prims[k];
-        int nv;
-        if (p.kind == NNBVH_PRIM_TRIANGLE) nv = 3;
-        else if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) nv = 4;
-        else {
+        int nv, nslots;
+        if (p.kind == NNBVH_PRIM_TRIANGLE) nv = nslots = 3;
+        else if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) nv = nslots = 4;
+        else if (p.kind == NNBVH_PRIM_INSTANCE) {
+            nv = 0;
+            nslots = 6;
+            if (p.v[0] < 0 || p.v[0] >= n_instances) {
+                set_error("scene_create: instance index out of range");
+                return nullptr;
+            }
+        } else {
             set_error("scene_create: unknown primitive kind");
             return nullptr;
         }
@@ -214,29 +250,14 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
                 set_error("scene_create: vertex index out of range");
                 return nullptr;
             }
-        slot_of[(size_t)k + 1] = slot_of[(size_t)k] + nv;
+        slot_of[(size_t)k + 1] = slot_of[(size_t)k] + nslots;
     }
     const int64_t n_slots = slot_of[(size_t)n_prims];
-    if (n_slots >= 0x7fffffffLL) {
+    if (n_slots >= 0x7ffffffeLL) {
         set_error("scene_create: primitive stream exceeds 2^31 slots");
         return nullptr;
     }
-    std::vector<float> stream((size_t)n_slots * 4, 0.0f);
-    for (int k = 0; k < n_prims; ++k) {
-        const nnbvh_prim &p = prims[k];
-        const int nv = p.kind == NNBVH_PRIM_TRIANGLE ? 3 : 4;
-        float *s = &stream[(size_t)slot_of[(size_t)k] * 4];
-        for (int j = 0; j < nv; ++j) put3(s, 4 * j, verts + 3 * (size_t)p.v[j]);
-        uint32_t flags = (leaf_last[(size_t)k] ? kPrimLast : 0u) |
-                         (p.kind == NNBVH_PRIM_BILINEAR_PATCH ? kPrimPatch : 0u);
-        if (p.kind == NNBVH_PRIM_TRIANGLE &&
-            triangle_is_degenerate(verts + 3 * (size_t)p.v[0], verts + 3 * (size_t)p.v[1],
-                                   verts + 3 * (size_t)p.v[2]))
-            flags |= kPrimDegenerate;
-        std::memcpy(&s[3], &p.id, 4);
-        std::memcpy(&s[7], &flags, 4);
-    }
-    // interior records
+    // interior record numbers (global over all trees) and node refs
     std::vector<int> ord((size_t)n_nodes, -1);
     int n_interior = 0;
     for (int i = 0; i < n_nodes; ++i)
@@ -245,6 +266,35 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
         return nodes[i].nprims == 0 ? ord[(size_t)i]
                                     : (int32_t) ~(uint32_t)slot_of[(size_t)nodes[i].offset];
     };
+    std::vector<float> stream((size_t)n_slots * 4, 0.0f);
+    for (int k = 0; k < n_prims; ++k) {
+        const nnbvh_prim &p = prims[k];
+        float *s = &stream[(size_t)slot_of[(size_t)k] * 4];
+        uint32_t flags = leaf_last[(size_t)k] ? kPrimLast : 0u;
+        if (p.kind == NNBVH_PRIM_INSTANCE) {
+            const nnbvh_instance &in = instances[p.v[0]];
+            const nnbvh_linear_node &root = nodes[in.root];
+            flags |= kPrimInstance;
+            put3(s, 0, root.pmin);
+            put3(s, 4, root.pmax);
+            std::memcpy(&s[3], &p.v[0], 4);  // instance index (reported +1 in nnbvh_hit.instance)
+            std::memcpy(&s[7], &flags, 4);
+            std::memcpy(&s[8], in.prim_from_render, 48);
+            const int32_t rref = ref_of(in.root);
+            std::memcpy(&s[20], &rref, 4);
+            continue;
+        }
+        const int nv = p.kind == NNBVH_PRIM_TRIANGLE ? 3 : 4;
+        for (int j = 0; j < nv; ++j) put3(s, 4 * j, verts + 3 * (size_t)p.v[j]);
+        if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) flags |= kPrimPatch;
+        if (p.kind == NNBVH_PRIM_TRIANGLE &&
+            triangle_is_degenerate(verts + 3 * (size_t)p.v[0], verts + 3 * (size_t)p.v[1],
+                                   verts + 3 * (size_t)p.v[2]))
+            flags |= kPrimDegenerate;
+        std::memcpy(&s[3], &p.id, 4);
+        std::memcpy(&s[7], &flags, 4);
+    }
+    // interior records
     std::vector<WideNode> wide((size_t)std::max(n_interior, 1));
     std::memset(wide.data(), 0, wide.size() * sizeof(WideNode));
     for (int i = 0; i < n_nodes; ++i) {
@@ -280,6 +330,7 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
     std::memcpy(s->bounds, nodes[0].pmin, 12);
     std::memcpy(s->bounds + 3, nodes[0].pmax, 12);
     s->root_ref = ref_of(0);
+    s->instanced = n_instances > 0 ? 1 : 0;
     s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
     const size_t wide_bytes = wide.size() * sizeof(WideNode);
     const size_t prim_bytes = std::max<size_t>((size_t)n_slots, 1) * 16;
@@ -306,6 +357,42 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
     if (const char *e = std::getenv("NNBVH_PREFETCH")) nnbvh_scene_set_option(s, "prefetch", atoi(e));
     if (const char *e = std::getenv("NNBVH_PRIM_WEIGHT")) nnbvh_scene_set_option(s, "prim_weight", atoi(e));
     return s;
+}
+
+nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
+                                const nnbvh_prim *prims, int n_prims, const float *verts,
+                                int n_verts, int device) {
+    return create_scene(nodes, n_nodes, n_nodes, prims, n_prims, verts, n_verts, nullptr, 0, device);
+}
+
+nnbvh_scene *nnbvh_scene_create_instanced(const nnbvh_linear_node *nodes, int n_nodes,
+                                          int n_top_nodes, const nnbvh_prim *prims, int n_prims,
+                                          const float *verts, int n_verts,
+                                          const nnbvh_instance *instances, int n_instances,
+                                          int device) {
+    return create_scene(nodes, n_nodes, n_top_nodes, prims, n_prims, verts, n_verts, instances,
+                        n_instances, device);
+}
+
+void nnbvh_transform_bounds(const float m[12], const float in[6], float out[6]) {
+    // Transform::operator()(const Bounds3f&), util/transform.cpp:134-139: union of the 8
+    // transformed corners (Bounds3::Corner, vecmath.h:1284-1289; point transform
+    // util/transform.h:310-319 with w == 1)
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; ++k) {
+        mn[k] = std::numeric_limits<float>::max();
+        mx[k] = std::numeric_limits<float>::lowest();
+    }
+    for (int c = 0; c < 8; ++c) {
+        const float p[3] = {in[(c & 1) ? 3 : 0], in[(c & 2) ? 4 : 1], in[(c & 4) ? 5 : 2]};
+        for (int k = 0; k < 3; ++k) {
+            const float v = m[4 * k] * p[0] + m[4 * k + 1] * p[1] + m[4 * k + 2] * p[2] + m[4 * k + 3];
+            mn[k] = std::min(mn[k], v);
+            mx[k] = std::max(mx[k], v);
+        }
+    }
+    std::memcpy(out, mn, 12);
+    std::memcpy(out + 3, mx, 12);
 }
 
 void nnbvh_scene_destroy(nnbvh_scene *s) {
@@ -346,7 +433,7 @@ static int grid_blocks(nnbvh_scene *s, int mode) {
     if (per_cu <= 0) {
         TraceParams dummy{};
         int occ = 0;
-        if (launch_trace(mode, dummy, s->window, s->prefetch, 0, nullptr, &occ) != hipSuccess ||
+        if (launch_trace(mode, dummy, s->window, s->prefetch, s->instanced, 0, nullptr, &occ) != hipSuccess ||
             occ <= 0)
             occ = std::max(1, std::min(8, 160 / (s->window * 2)));
         per_cu = occ;
@@ -486,7 +573,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     int blocks = grid_blocks(s, mode);
     const int64_t need = (n + kBlockThreads - 1) / kBlockThreads;
     if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
-    if (!hip_ok(launch_trace(mode, p, s->window, s->prefetch, blocks, stream, nullptr),
+    if (!hip_ok(launch_trace(mode, p, s->window, s->prefetch, s->instanced, blocks, stream, nullptr),
                 "trace kernel launch"))
         return NNBVH_ERR_DEVICE;
     return NNBVH_OK;

@@ -264,8 +264,79 @@ DEV bool patch_test(const RayState &r, V3 rd, float tMax, V3 p00, V3 p10, V3 p01
     return true;
 }
 
+// ---- TransformedPrimitive's ray transform (two-level scenes) ------------------------------
+// Transform::ApplyInverse(const Ray&, Float *tMax), util/transform.h:416-429, on top of
+// Transform::ApplyInverse(const Point3fi&), util/transform.cpp:263-303 (exact-input branch), with
+// the CPU forms of the directed-rounding helpers (util/float.h:163-260: NextFloatUp/Down of the
+// round-to-nearest result) and Interval::{FromValueAndError, +=, /, Midpoint, Width}
+// (util/math.h:829-853, 874-876, 1028-1036).
+DEV float next_up(float v) {
+    if (__builtin_isinf(v) && v > 0.f) return v;
+    if (v == -0.f) v = 0.f;
+    unsigned ui = __float_as_uint(v);
+    if (v >= 0) ++ui;
+    else --ui;
+    return __uint_as_float(ui);
+}
+DEV float next_down(float v) {
+    if (__builtin_isinf(v) && v < 0.f) return v;
+    if (v == 0.f) v = -0.f;
+    unsigned ui = __float_as_uint(v);
+    if (v > 0) --ui;
+    else ++ui;
+    return __uint_as_float(ui);
+}
+struct Ivl {
+    float lo, hi;
+};
+DEV Ivl ivl(float a, float b) { return {(b < a) ? b : a, (a < b) ? b : a}; }
+DEV Ivl ivl_from_value_and_error(float v, float err) {
+    if (err == 0) return {v, v};
+    return {next_down(v + (-err)), next_up(v + err)};
+}
+DEV Ivl ivl_add_f(Ivl a, float f) { return ivl(next_down(a.lo + f), next_up(a.hi + f)); }
+DEV Ivl ivl_div_f(Ivl i, float f) {
+    if (f == 0) return ivl(-__builtin_inff(), __builtin_inff());
+    if (f > 0) return ivl(next_down(i.lo / f), next_up(i.hi / f));
+    return ivl(next_down(i.hi / f), next_up(i.lo / f));
+}
+// rows r0, r1, r2 of the 3x4 inverse matrix
+DEV void apply_inverse_ray(float4 r0, float4 r1, float4 r2, V3 o, V3 d, float &tMax, V3 &oOut,
+                           V3 &dOut) {
+    constexpr float g3 = gamma_f(3);
+    const float px = (r0.x * o.x + r0.y * o.y) + (r0.z * o.z + r0.w);
+    const float py = (r1.x * o.x + r1.y * o.y) + (r1.z * o.z + r1.w);
+    const float pz = (r2.x * o.x + r2.y * o.y) + (r2.z * o.z + r2.w);
+    const float ex0 = g3 * (__builtin_fabsf(r0.x * o.x) + __builtin_fabsf(r0.y * o.y) + __builtin_fabsf(r0.z * o.z));
+    const float ey0 = g3 * (__builtin_fabsf(r1.x * o.x) + __builtin_fabsf(r1.y * o.y) + __builtin_fabsf(r1.z * o.z));
+    const float ez0 = g3 * (__builtin_fabsf(r2.x * o.x) + __builtin_fabsf(r2.y * o.y) + __builtin_fabsf(r2.z * o.z));
+    const float wp = (0.f * o.x + 0.f * o.y) + (0.f * o.z + 1.f);
+    Ivl xp = ivl_from_value_and_error(px, ex0), yp = ivl_from_value_and_error(py, ey0),
+        zp = ivl_from_value_and_error(pz, ez0);
+    if (!(wp == 1)) {
+        xp = ivl_div_f(xp, wp);
+        yp = ivl_div_f(yp, wp);
+        zp = ivl_div_f(zp, wp);
+    }
+    const float dx = r0.x * d.x + r0.y * d.y + r0.z * d.z;
+    const float dy = r1.x * d.x + r1.y * d.y + r1.z * d.z;
+    const float dz = r2.x * d.x + r2.y * d.y + r2.z * d.z;
+    const float len2 = dx * dx + dy * dy + dz * dz;
+    if (len2 > 0) {
+        const float ex = (xp.hi - xp.lo) / 2, ey = (yp.hi - yp.lo) / 2, ez = (zp.hi - zp.lo) / 2;
+        const float dt = (__builtin_fabsf(dx) * ex + __builtin_fabsf(dy) * ey + __builtin_fabsf(dz) * ez) / len2;
+        xp = ivl_add_f(xp, dx * dt);
+        yp = ivl_add_f(yp, dy * dt);
+        zp = ivl_add_f(zp, dz * dt);
+        tMax -= dt;
+    }
+    oOut = {(xp.lo + xp.hi) / 2, (yp.lo + yp.hi) / 2, (zp.lo + zp.hi) / 2};
+    dOut = {dx, dy, dz};
+}
+
 // ------------------------------------------------------------------------------------
-constexpr int kDone = (int)0x80000000;  // never a leaf ref: ~slot with slot = 0x7fffffff
+constexpr int kDone = (int)0x80000000;    // never a leaf ref: ~slot with slot = 0x7fffffff
+constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is exhausted (slot 0x7ffffffe)
 
 // MODE 0: closest hit (counts always)
 // MODE 1: any hit with exact node-visit / prim-test counts (pushes every far child)
@@ -291,8 +362,14 @@ constexpr int kDone = (int)0x80000000;  // never a leaf ref: ~slot with slot = 0
 #ifndef NNBVH_MINW_ANY
 #define NNBVH_MINW_ANY 6
 #endif
-template <int MODE, int W, int PF>
-__global__ __launch_bounds__(kBlockThreads, (MODE == 0 ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY))
+//
+// INST = 1: the scene is two-level (TransformedPrimitive leaves, cpu/primitive.cpp:112-131).  An
+// instance primitive saves the lane's ray state in LDS, transforms the ray with the reference's
+// interval arithmetic, traverses the child tree ABOVE the current stack level (`floor`) and
+// returns to the outer leaf when the child is exhausted.  Compiled separately so that
+// single-level scenes pay nothing for it.
+template <int MODE, int W, int PF, int INST>
+__global__ __launch_bounds__(kBlockThreads, (INST ? 1 : (MODE == 0 ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY)))
 void trace_kernel(TraceParams p) {
     __shared__ int s_ref[kBlockThreads / 64][W][64];
     __shared__ float s_key[kBlockThreads / 64][W][64];
@@ -300,7 +377,13 @@ void trace_kernel(TraceParams p) {
     // ray index (read when the ray retires), the direction (read by the patch test only; the
     // triangle test uses the precomputed shear) and, closest hit, the current best hit
     // (written on an accepted hit, read at retire).  Frees 4 / 8 registers per lane.
-    constexpr int kColdRi = 0, kColdD = 1, kColdHit = 4, kColdFields = (MODE == 0) ? 8 : 4;
+    constexpr int kColdRi = 0, kColdD = 1, kColdHit = 4, kColdBase = (MODE == 0) ? 8 : 4;
+    // two-level scenes: the outer ray saved while a child tree is traversed
+    constexpr int kSaveO = kColdBase, kSaveInv = kColdBase + 3, kSaveShear = kColdBase + 6,
+                  kSaveKz = kColdBase + 9, kSaveTmax = kColdBase + 10, kSaveD = kColdBase + 11,
+                  kResume = kColdBase + 14, kCurInst = kColdBase + 15, kHitInst = kColdBase + 16,
+                  kInnerHit = kColdBase + 17;
+    constexpr int kColdFields = kColdBase + (INST ? 18 : 0);
     __shared__ float s_cold[kBlockThreads / 64][kColdFields][64];
 
     const int lane = threadIdx.x & 63;
@@ -328,13 +411,14 @@ void trace_kernel(TraceParams p) {
     float tMax = 0.0f;
     int visited = 0, tests = 0;
     int cur = kDone, sp = 0, base = 0;
+    int floor = -1;      // INST: stack level the current child traversal must not pop below
     bool found = false;  // MODE 1/2
     bool exhausted = false;
     unsigned pf0 = 0, pf1 = 0;  // landing registers of the child-record prefetches
 
     // pop entries until one whose deferred box test passes with the current tMax
     auto pop_next = [&]() -> int {
-        while (sp > 0) {
+        while (sp > ((INST && floor > 0) ? floor : 0)) {
             --sp;
             int ref = sref[sp & (W - 1)][lane];  // always an LDS read (stale if spilled)
             float key = skey[sp & (W - 1)][lane];
@@ -351,7 +435,7 @@ void trace_kernel(TraceParams p) {
             if (MODE != 2) visited += 1;
             if (key < tMax) return ref;
         }
-        return kDone;
+        return (INST && floor >= 0) ? kReturn : kDone;
     };
 
     for (;;) {
@@ -393,7 +477,7 @@ void trace_kernel(TraceParams p) {
                     h1.x = cold[kColdHit + 3][lane];
                     h1.y = __int_as_float(visited);
                     h1.z = __int_as_float(tests);
-                    h1.w = 0.0f;
+                    h1.w = INST ? cold[kHitInst][lane] : 0.0f;  // 0 / instance index + 1 (bit pattern)
                     float4 *out = reinterpret_cast<float4 *>(p.hits) + 2 * (long)ri;
                     out[0] = h0;
                     out[1] = h1;
@@ -446,6 +530,11 @@ void trace_kernel(TraceParams p) {
                     cold[kColdHit + 2][lane] = 0.0f;
                     cold[kColdHit + 3][lane] = 0.0f;
                 }
+                if (INST) {
+                    cold[kHitInst][lane] = 0.0f;
+                    cold[kCurInst][lane] = 0.0f;
+                    floor = -1;
+                }
                 visited = 1;  // the root
                 tests = 0;
                 found = false;
@@ -463,9 +552,65 @@ void trace_kernel(TraceParams p) {
         if (sP > sI || nInt == 0) {
             // ---- primitive step: lanes with a pending leaf test ONE primitive -----------
             if (!isInt && !isIdle) {
+                if (INST && cur == kReturn) {
+                    // the child tree of an instance is exhausted: restore the outer ray
+                    // (TransformedPrimitive::Intersect returns; `tMax = si->tHit` if it hit)
+                    const bool innerHit = cold[kInnerHit][lane] != 0.0f;
+                    r.o = {cold[kSaveO][lane], cold[kSaveO + 1][lane], cold[kSaveO + 2][lane]};
+                    r.inv = {cold[kSaveInv][lane], cold[kSaveInv + 1][lane], cold[kSaveInv + 2][lane]};
+                    r.sx = cold[kSaveShear][lane];
+                    r.sy = cold[kSaveShear + 1][lane];
+                    r.sz = cold[kSaveShear + 2][lane];
+                    r.kz = __float_as_int(cold[kSaveKz][lane]);
+                    cold[kColdD][lane] = cold[kSaveD][lane];
+                    cold[kColdD + 1][lane] = cold[kSaveD + 1][lane];
+                    cold[kColdD + 2][lane] = cold[kSaveD + 2][lane];
+                    if (!innerHit) tMax = cold[kSaveTmax][lane];
+                    cold[kCurInst][lane] = 0.0f;
+                    floor = -1;
+                    const int resume = __float_as_int(cold[kResume][lane]);
+                    cur = (resume == kDone) ? pop_next() : resume;
+                }
+                if (cur < 0 && cur != kDone && !(INST && cur == kReturn)) {
                 const int slot = ~cur;
                 const float4 s0 = p.prims[slot], s1 = p.prims[slot + 1], s2 = p.prims[slot + 2];
                 const unsigned flags = __float_as_uint(s1.w);
+                if (INST && (flags & kPrimInstance)) {
+                    // TransformedPrimitive::Intersect / IntersectP (cpu/primitive.cpp:112-131)
+                    const float4 s3 = p.prims[slot + 3], s4 = p.prims[slot + 4], s5 = p.prims[slot + 5];
+                    const V3 dOuter = {cold[kColdD][lane], cold[kColdD + 1][lane], cold[kColdD + 2][lane]};
+                    cold[kSaveO][lane] = r.o.x;
+                    cold[kSaveO + 1][lane] = r.o.y;
+                    cold[kSaveO + 2][lane] = r.o.z;
+                    cold[kSaveInv][lane] = r.inv.x;
+                    cold[kSaveInv + 1][lane] = r.inv.y;
+                    cold[kSaveInv + 2][lane] = r.inv.z;
+                    cold[kSaveShear][lane] = r.sx;
+                    cold[kSaveShear + 1][lane] = r.sy;
+                    cold[kSaveShear + 2][lane] = r.sz;
+                    cold[kSaveKz][lane] = __int_as_float(r.kz);
+                    cold[kSaveTmax][lane] = tMax;
+                    cold[kSaveD][lane] = dOuter.x;
+                    cold[kSaveD + 1][lane] = dOuter.y;
+                    cold[kSaveD + 2][lane] = dOuter.z;
+                    cold[kResume][lane] = __int_as_float((flags & kPrimLast) ? kDone : ~(slot + 6));
+                    cold[kCurInst][lane] = __int_as_float(__float_as_int(s0.w) + 1);
+                    cold[kInnerHit][lane] = 0.0f;
+                    V3 oIn, dIn;
+                    apply_inverse_ray(s2, s3, s4, r.o, dOuter, tMax, oIn, dIn);
+                    r.o = oIn;
+                    cold[kColdD][lane] = dIn.x;
+                    cold[kColdD + 1][lane] = dIn.y;
+                    cold[kColdD + 2][lane] = dIn.z;
+                    r.inv = {1.0f / dIn.x, 1.0f / dIn.y, 1.0f / dIn.z};
+                    ray_shear(r, dIn);
+                    floor = sp;
+                    if (MODE != 2) visited += 1;  // the child aggregate's root
+                    float tEntry;
+                    const bool rootHit = slab_partial(s0.x, s0.y, s0.z, s1.x, s1.y, s1.z, r, tEntry) &&
+                                         (tEntry < tMax);
+                    cur = rootHit ? __float_as_int(s5.x) : kReturn;
+                } else {
                 tests += 1;
                 bool hit;
                 float x0, x1, x2, th;
@@ -489,6 +634,10 @@ void trace_kernel(TraceParams p) {
                         cold[kColdHit + 2][lane] = x1;
                         cold[kColdHit + 3][lane] = x2;
                         tMax = th;
+                        if (INST) {
+                            cold[kHitInst][lane] = cold[kCurInst][lane];
+                            cold[kInnerHit][lane] = 1.0f;
+                        }
                     } else {
                         found = true;
                     }
@@ -496,6 +645,8 @@ void trace_kernel(TraceParams p) {
                 if (MODE != 0 && found) cur = kDone;            // aggregates.cpp:597-602
                 else if (flags & kPrimLast) cur = pop_next();   // leaf finished
                 else cur = ~next;
+                }
+                }
             }
         } else {
             // ---- interior step(s): up to p.intRepeat in a row before the next scheduling
@@ -563,14 +714,14 @@ void trace_kernel(TraceParams p) {
 }
 
 // ------------------------------------------------------------------------------------
-template <int MODE, int W, int PF>
+template <int MODE, int W, int PF, int INST>
 static hipError_t launch_one(const TraceParams &p, int blocks, hipStream_t stream, int *occupancy) {
     if (occupancy) {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, trace_kernel<MODE, W, PF>,
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, trace_kernel<MODE, W, PF, INST>,
                                                             kBlockThreads, 0);
     }
-    hipLaunchKernelGGL((trace_kernel<MODE, W, PF>), dim3((unsigned)blocks), dim3(kBlockThreads), 0,
-                       stream, p);
+    hipLaunchKernelGGL((trace_kernel<MODE, W, PF, INST>), dim3((unsigned)blocks), dim3(kBlockThreads),
+                       0, stream, p);
     return hipGetLastError();
 }
 
@@ -578,28 +729,30 @@ template <int MODE, int PF>
 static hipError_t launch_window(const TraceParams &p, int window, int blocks, hipStream_t stream,
                                 int *occupancy) {
     switch (window) {
-    case 4: return launch_one<MODE, 4, PF>(p, blocks, stream, occupancy);
-    case 8: return launch_one<MODE, 8, PF>(p, blocks, stream, occupancy);
-    case 16: return launch_one<MODE, 16, PF>(p, blocks, stream, occupancy);
+    case 4: return launch_one<MODE, 4, PF, 0>(p, blocks, stream, occupancy);
+    case 8: return launch_one<MODE, 8, PF, 0>(p, blocks, stream, occupancy);
+    case 16: return launch_one<MODE, 16, PF, 0>(p, blocks, stream, occupancy);
     default: return hipErrorInvalidValue;
     }
 }
 
 template <int MODE>
-static hipError_t launch_mode(const TraceParams &p, int window, int prefetch, int blocks,
-                              hipStream_t stream, int *occupancy) {
+static hipError_t launch_mode(const TraceParams &p, int window, int prefetch, int instanced,
+                              int blocks, hipStream_t stream, int *occupancy) {
+    // two-level scenes: one instance of the kernel (window 8, no prefetch)
+    if (instanced) return launch_one<MODE, 8, 0, 1>(p, blocks, stream, occupancy);
     if (prefetch == 1) return launch_window<MODE, 1>(p, window, blocks, stream, occupancy);
     if (prefetch == 2) return launch_window<MODE, 2>(p, window, blocks, stream, occupancy);
     return launch_window<MODE, 0>(p, window, blocks, stream, occupancy);
 }
 
 // occupancy != nullptr: no launch, only report resident blocks per CU for that instance
-hipError_t launch_trace(int mode, const TraceParams &p, int window, int prefetch, int blocks,
-                        hipStream_t stream, int *occupancy) {
+hipError_t launch_trace(int mode, const TraceParams &p, int window, int prefetch, int instanced,
+                        int blocks, hipStream_t stream, int *occupancy) {
     switch (mode) {
-    case 0: return launch_mode<0>(p, window, prefetch, blocks, stream, occupancy);
-    case 1: return launch_mode<1>(p, window, prefetch, blocks, stream, occupancy);
-    case 2: return launch_mode<2>(p, window, prefetch, blocks, stream, occupancy);
+    case 0: return launch_mode<0>(p, window, prefetch, instanced, blocks, stream, occupancy);
+    case 1: return launch_mode<1>(p, window, prefetch, instanced, blocks, stream, occupancy);
+    case 2: return launch_mode<2>(p, window, prefetch, instanced, blocks, stream, occupancy);
     default: return hipErrorInvalidValue;
     }
 }

@@ -35,6 +35,11 @@ static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 constexpr uint32_t kPrimLast = 1u;
 constexpr uint32_t kPrimPatch = 2u;
 constexpr uint32_t kPrimDegenerate = 4u;
+// instance (TransformedPrimitive) record, 6 slots:
+//   {childRoot.pmin.xyz, instance index} {childRoot.pmax.xyz, flags}
+//   {mInv row 0} {mInv row 1} {mInv row 2}  (renderFromPrimitive inverse, 3x4)
+//   {child root ref, 0, 0, 0}
+constexpr uint32_t kPrimInstance = 8u;
 
 constexpr int kMaxStack = 64;  // the reference's nodesToVisit[64], aggregates.cpp:538
 

@@ -323,6 +323,123 @@ void orc_bilinear_patch_batch(const float *o3, const float *d3, const float *tma
     }
 }
 
+/* ---- the ray transform of TransformedPrimitive -------------------------------------------
+ * Transform::ApplyInverse(const Ray&, Float *tMax)   util/transform.h:416-429
+ * Transform::ApplyInverse(const Point3fi&)           util/transform.cpp:263-303 (exact-input branch)
+ * Interval::FromValueAndError, operator+=, Midpoint, Width   util/math.h:829-853, 874-876, 905-908
+ * NextFloatUp/Down, Add/Sub/DivRound* (CPU forms)    util/float.h:163-193, 199-260 */
+typedef struct {
+    float lo, hi;
+} orc_ivl;
+
+static inline float next_up(float v) {
+    if (isinf(v) && v > 0.f) return v;
+    if (v == -0.f) v = 0.f;
+    uint32_t ui;
+    memcpy(&ui, &v, 4);
+    if (v >= 0) ++ui;
+    else --ui;
+    memcpy(&v, &ui, 4);
+    return v;
+}
+static inline float next_down(float v) {
+    if (isinf(v) && v < 0.f) return v;
+    if (v == 0.f) v = -0.f;
+    uint32_t ui;
+    memcpy(&ui, &v, 4);
+    if (v > 0) --ui;
+    else ++ui;
+    memcpy(&v, &ui, 4);
+    return v;
+}
+static inline orc_ivl ivl(float a, float b) { /* Interval(low, high): min / max, math.h:825-826 */
+    orc_ivl r;
+    r.lo = (b < a) ? b : a;
+    r.hi = (a < b) ? b : a;
+    return r;
+}
+static inline orc_ivl ivl_from_value_and_error(float v, float err) { /* math.h:829-838 */
+    orc_ivl i;
+    if (err == 0) i.lo = i.hi = v;
+    else {
+        i.lo = next_down(v + (-err)); /* SubRoundDown(v, err) = AddRoundDown(v, -err) */
+        i.hi = next_up(v + err);
+    }
+    return i;
+}
+static inline orc_ivl ivl_add_f(orc_ivl a, float f) { /* `x += v.x`: math.h:922 -> 905-908 -> 874-876 */
+    return ivl(next_down(a.lo + f), next_up(a.hi + f));
+}
+static inline orc_ivl ivl_div_f(orc_ivl i, float f) { /* math.h:1028-1037 */
+    if (f == 0) return ivl(-INFINITY, INFINITY);
+    if (f > 0) return ivl(next_down(i.lo / f), next_up(i.hi / f));
+    return ivl(next_down(i.hi / f), next_up(i.lo / f));
+}
+
+void orc_apply_inverse_ray(const float mi[12], const float o[3], const float d[3], float tmax,
+                           float out[7]) {
+    const float x = o[0], y = o[1], z = o[2]; /* Float(p.x): midpoint of an exact interval */
+    const float g3 = orc_gamma(3);
+    float p[3], e[3];
+    for (int k = 0; k < 3; ++k) {
+        const float *r = mi + 4 * k;
+        p[k] = (r[0] * x + r[1] * y) + (r[2] * z + r[3]);
+        e[k] = g3 * (fabsf(r[0] * x) + fabsf(r[1] * y) + fabsf(r[2] * z));
+    }
+    const float wp = (0.f * x + 0.f * y) + (0.f * z + 1.f); /* row 3 of an affine inverse */
+    orc_ivl xp = ivl_from_value_and_error(p[0], e[0]);
+    orc_ivl yp = ivl_from_value_and_error(p[1], e[1]);
+    orc_ivl zp = ivl_from_value_and_error(p[2], e[2]);
+    if (!(wp == 1)) {
+        xp = ivl_div_f(xp, wp);
+        yp = ivl_div_f(yp, wp);
+        zp = ivl_div_f(zp, wp);
+    }
+    /* Transform::ApplyInverse(Vector3f), transform.h:401-406 */
+    float dx = mi[0] * d[0] + mi[1] * d[1] + mi[2] * d[2];
+    float dy = mi[4] * d[0] + mi[5] * d[1] + mi[6] * d[2];
+    float dz = mi[8] * d[0] + mi[9] * d[1] + mi[10] * d[2];
+    float len2 = dx * dx + dy * dy + dz * dz;
+    if (len2 > 0) { /* transform.h:420-427 */
+        float ex = (xp.hi - xp.lo) / 2, ey = (yp.hi - yp.lo) / 2, ez = (zp.hi - zp.lo) / 2;
+        float dt = (fabsf(dx) * ex + fabsf(dy) * ey + fabsf(dz) * ez) / len2;
+        xp = ivl_add_f(xp, dx * dt);
+        yp = ivl_add_f(yp, dy * dt);
+        zp = ivl_add_f(zp, dz * dt);
+        tmax -= dt;
+    }
+    out[0] = (xp.lo + xp.hi) / 2; /* Point3f(o): Interval::Midpoint, math.h:851 */
+    out[1] = (yp.lo + yp.hi) / 2;
+    out[2] = (zp.lo + zp.hi) / 2;
+    out[3] = dx;
+    out[4] = dy;
+    out[5] = dz;
+    out[6] = tmax;
+}
+
+void orc_apply_inverse_ray_batch(const float *mi12, const float *o3, const float *d3,
+                                 const float *tmax, int n, float *out7) {
+    for (int i = 0; i < n; ++i)
+        orc_apply_inverse_ray(mi12 + 12 * i, o3 + 3 * i, d3 + 3 * i, tmax[i], out7 + 7 * i);
+}
+
+/* Transform::operator()(const Bounds3f&), util/transform.cpp:134-139, with the point
+ * transform of util/transform.h:310-319 and Bounds3::Corner (vecmath.h:1284-1289) */
+void orc_transform_bounds(const float m[12], const float in[6], float out[6]) {
+    float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f};
+    float mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+    for (int c = 0; c < 8; ++c) {
+        float p[3] = {in[(c & 1) ? 3 : 0], in[(c & 2) ? 4 : 1], in[(c & 4) ? 5 : 2]};
+        for (int k = 0; k < 3; ++k) {
+            float v = m[4 * k] * p[0] + m[4 * k + 1] * p[1] + m[4 * k + 2] * p[2] + m[4 * k + 3];
+            if (v < mn[k]) mn[k] = v;
+            if (mx[k] < v) mx[k] = v;
+        }
+    }
+    memcpy(out, mn, 12);
+    memcpy(out + 3, mx, 12);
+}
+
 /* ---- primitive dispatch (cpu/primitive.cpp:24-32 -> shapes.cpp:320-358, 1131-1156) --- */
 static inline int prim_test(const orc_prim *p, const float *verts, const float o[3],
                             const float d[3], float tmax, float res[4]) {
@@ -344,18 +461,18 @@ static inline int prim_test(const orc_prim *p, const float *verts, const float o
 }
 
 /* ---- BVHAggregate::Intersect, aggregates.cpp:529-579 -------------------------------- */
-static void closest_one(const orc_node *nodes, const orc_prim *prims, const float *verts,
-                        const orc_ray *ray, orc_hit *hit) {
-    float tmax = ray->tmax;
-    const float *o = ray->o, *d = ray->d;
+/* One BVHAggregate::Intersect over the tree rooted at `root`; hit/tmax/counters are carried
+ * by the caller so that a TransformedPrimitive's child aggregate (cpu/primitive.cpp:112-126)
+ * adds to the same bvhNodesVisited / nTriTests as the reference's global counters do. */
+static void closest_tree(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                         const orc_instance *instances, int root, const float o[3],
+                         const float d[3], float *tmax_io, orc_hit *hit, int *visited_io,
+                         int *tests_io, int instance_tag) {
+    float tmax = *tmax_io;
     float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
     int neg[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
-    int to_visit = 0, cur = 0, visited = 0, tests = 0;
+    int to_visit = 0, cur = root, visited = *visited_io, tests = *tests_io;
     int stack[64];
-    hit->prim = -1;
-    hit->t = tmax;
-    hit->b0 = hit->b1 = hit->b2 = 0.0f;
-    hit->pad = 0;
     for (;;) {
         ++visited;
         const orc_node *nd = &nodes[cur];
@@ -364,6 +481,21 @@ static void closest_one(const orc_node *nodes, const orc_prim *prims, const floa
                 for (int i = 0; i < nd->nprims; ++i) {
                     const orc_prim *p = &prims[nd->offset + i];
                     float r[4];
+                    if (p->kind == 2) { /* TransformedPrimitive::Intersect */
+                        const orc_instance *in = &instances[p->v[0]];
+                        float x[7];
+                        orc_apply_inverse_ray(in->m_inv, o, d, tmax, x);
+                        float inner_tmax = x[6];
+                        orc_hit inner = *hit;
+                        inner.prim = -1;
+                        closest_tree(nodes, prims, verts, instances, in->root, x, x + 3,
+                                     &inner_tmax, &inner, &visited, &tests, p->v[0] + 1);
+                        if (inner.prim >= 0) { /* si = primSi; tMax = si->tHit */
+                            *hit = inner;
+                            tmax = inner.t;
+                        }
+                        continue;
+                    }
                     ++tests;
                     if (prim_test(p, verts, o, d, tmax, r)) {
                         hit->prim = p->id;
@@ -371,6 +503,7 @@ static void closest_one(const orc_node *nodes, const orc_prim *prims, const floa
                         hit->b1 = r[1];
                         hit->b2 = r[2];
                         hit->t = r[3];
+                        hit->instance = instance_tag;
                         tmax = r[3];
                     }
                 }
@@ -390,18 +523,32 @@ static void closest_one(const orc_node *nodes, const orc_prim *prims, const floa
             cur = stack[--to_visit];
         }
     }
+    *tmax_io = tmax;
+    *visited_io = visited;
+    *tests_io = tests;
+}
+
+static void closest_one(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                        const orc_instance *instances, const orc_ray *ray, orc_hit *hit) {
+    float tmax = ray->tmax;
+    int visited = 0, tests = 0;
+    hit->prim = -1;
+    hit->t = tmax;
+    hit->b0 = hit->b1 = hit->b2 = 0.0f;
+    hit->instance = 0;
+    closest_tree(nodes, prims, verts, instances, 0, ray->o, ray->d, &tmax, hit, &visited, &tests, 0);
+    if (hit->prim < 0) hit->t = ray->tmax;
     hit->nodes_visited = visited;
     hit->prim_tests = tests;
 }
 
 /* ---- BVHAggregate::IntersectP, aggregates.cpp:581-624 ------------------------------- */
-static int any_one(const orc_node *nodes, const orc_prim *prims, const float *verts,
-                   const orc_ray *ray, int *visited_out, int *tests_out) {
-    float tmax = ray->tmax;
-    const float *o = ray->o, *d = ray->d;
+static int any_tree(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                    const orc_instance *instances, int root, const float o[3], const float d[3],
+                    float tmax, int *visited_io, int *tests_io) {
     float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
     int neg[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
-    int to_visit = 0, cur = 0, visited = 0, tests = 0, found = 0;
+    int to_visit = 0, cur = root, visited = *visited_io, tests = *tests_io, found = 0;
     int stack[64];
     for (;;) {
         ++visited;
@@ -409,9 +556,21 @@ static int any_one(const orc_node *nodes, const orc_prim *prims, const float *ve
         if (slab_test(nd->pmin, nd->pmax, o, tmax, inv, neg)) {
             if (nd->nprims > 0) {
                 for (int i = 0; i < nd->nprims; ++i) {
+                    const orc_prim *p = &prims[nd->offset + i];
                     float r[4];
+                    if (p->kind == 2) { /* TransformedPrimitive::IntersectP, primitive.cpp:128-131 */
+                        const orc_instance *in = &instances[p->v[0]];
+                        float x[7];
+                        orc_apply_inverse_ray(in->m_inv, o, d, tmax, x);
+                        if (any_tree(nodes, prims, verts, instances, in->root, x, x + 3, x[6],
+                                     &visited, &tests)) {
+                            found = 1;
+                            goto done;
+                        }
+                        continue;
+                    }
                     ++tests;
-                    if (prim_test(&prims[nd->offset + i], verts, o, d, tmax, r)) {
+                    if (prim_test(p, verts, o, d, tmax, r)) {
                         found = 1;
                         goto done;
                     }
@@ -433,6 +592,17 @@ static int any_one(const orc_node *nodes, const orc_prim *prims, const float *ve
         }
     }
 done:
+    *visited_io = visited;
+    *tests_io = tests;
+    return found;
+}
+
+static int any_one(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                   const orc_instance *instances, const orc_ray *ray, int *visited_out,
+                   int *tests_out) {
+    int visited = 0, tests = 0;
+    int found = any_tree(nodes, prims, verts, instances, 0, ray->o, ray->d, ray->tmax, &visited,
+                         &tests);
     *visited_out = visited;
     *tests_out = tests;
     return found;
@@ -443,6 +613,7 @@ typedef struct {
     const orc_node *nodes;
     const orc_prim *prims;
     const float *verts;
+    const orc_instance *instances;
     const orc_ray *rays;
     int64_t begin, end;
     orc_hit *hits;
@@ -457,12 +628,12 @@ static void *orc_worker(void *arg) {
     for (int64_t i = j->begin; i < j->end; ++i) {
         if (j->any) {
             int v, t;
-            int f = any_one(j->nodes, j->prims, j->verts, &j->rays[i], &v, &t);
+            int f = any_one(j->nodes, j->prims, j->verts, j->instances, &j->rays[i], &v, &t);
             j->occ[i] = (uint8_t)f;
             if (j->visited) j->visited[i] = v;
             if (j->tests) j->tests[i] = t;
         } else {
-            closest_one(j->nodes, j->prims, j->verts, &j->rays[i], &j->hits[i]);
+            closest_one(j->nodes, j->prims, j->verts, j->instances, &j->rays[i], &j->hits[i]);
         }
     }
     return NULL;
@@ -520,6 +691,38 @@ void orc_intersect_any(const orc_node *nodes, int n_nodes, const orc_prim *prims
     orc_run(j, n, nthreads);
 }
 
+void orc_intersect_closest_inst(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                                const orc_instance *instances, const orc_ray *rays, int64_t n,
+                                orc_hit *hits, int nthreads) {
+    orc_job j;
+    memset(&j, 0, sizeof j);
+    j.nodes = nodes;
+    j.prims = prims;
+    j.verts = verts;
+    j.instances = instances;
+    j.rays = rays;
+    j.hits = hits;
+    orc_run(j, n, nthreads);
+}
+
+void orc_intersect_any_inst(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                            const orc_instance *instances, const orc_ray *rays, int64_t n,
+                            uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests,
+                            int nthreads) {
+    orc_job j;
+    memset(&j, 0, sizeof j);
+    j.nodes = nodes;
+    j.prims = prims;
+    j.verts = verts;
+    j.instances = instances;
+    j.rays = rays;
+    j.occ = occluded;
+    j.visited = nodes_visited;
+    j.tests = prim_tests;
+    j.any = 1;
+    orc_run(j, n, nthreads);
+}
+
 void orc_brute_closest(const orc_prim *prims, int n_prims, const float *verts,
                        const orc_ray *rays, int64_t n, orc_hit *hits) {
     for (int64_t i = 0; i < n; ++i) {
@@ -530,7 +733,7 @@ void orc_brute_closest(const orc_prim *prims, int n_prims, const float *verts,
         h->t = tmax;
         h->b0 = h->b1 = h->b2 = 0.0f;
         h->nodes_visited = 0;
-        h->pad = 0;
+        h->instance = 0;
         for (int k = 0; k < n_prims; ++k) {
             float r[4];
             if (prim_test(&prims[k], verts, ray->o, ray->d, tmax, r)) {

@@ -32,10 +32,19 @@ typedef struct {
  * Triangle{meshIndex,triIndex} / BilinearPatch{meshIndex,blpIndex} handle
  * (shapes.h:1188, 1535) flattened to global vertex indices. */
 typedef struct {
-    int32_t kind; /* 0 = triangle (v[0..2]), 1 = bilinear patch (v = p00,p10,p01,p11) */
+    int32_t kind; /* 0 = triangle (v[0..2]), 1 = bilinear patch (v = p00,p10,p01,p11), 2 = instance (v[0]) */
     int32_t id;   /* caller's original primitive index, returned on a hit */
     int32_t v[4];
 } orc_prim;
+
+/* TransformedPrimitive (cpu/primitive.h:148-172): a child BVHAggregate behind a static
+ * render-from-primitive transform.  A top-level primitive of kind 2 names one by v[0]. */
+typedef struct {
+    float m[12];      /* renderFromPrimitive, rows 0..2 of the 4x4 (row 3 = 0 0 0 1) */
+    float m_inv[12];  /* its inverse, same layout */
+    int32_t root;     /* index of the child tree's root in the shared node array */
+    int32_t n_nodes;  /* nodes of the child tree (contiguous from root) */
+} orc_instance;
 
 typedef struct {
     float o[3];
@@ -50,7 +59,7 @@ typedef struct {
     float b0, b1, b2; /* triangle: barycentrics; patch: b0=u, b1=v, b2=0 */
     int32_t nodes_visited;
     int32_t prim_tests;
-    int32_t pad;
+    int32_t instance; /* 0 = hit in the top level (or miss); k+1 = hit inside instance k */
 } orc_hit;
 
 /* leaf tests and slab test on single inputs (return 1 = hit) */
@@ -77,6 +86,24 @@ void orc_intersect_any(const orc_node *nodes, int n_nodes, const orc_prim *prims
                        const float *verts, const orc_ray *rays, int64_t n,
                        uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests,
                        int nthreads);
+
+/* Transform::ApplyInverse(const Ray&, Float *tMax) (util/transform.h:416-429) for an affine
+ * transform given by the 3x4 inverse matrix: out = o'[3], d'[3], tmax'. */
+void orc_apply_inverse_ray(const float m_inv[12], const float o[3], const float d[3], float tmax,
+                           float out7[7]);
+void orc_apply_inverse_ray_batch(const float *m_inv12, const float *o3, const float *d3,
+                                 const float *tmax, int n, float *out7);
+/* Transform::operator()(const Bounds3f&) (util/transform.cpp): bounds of the 8 transformed corners */
+void orc_transform_bounds(const float m[12], const float in6[6], float out6[6]);
+
+/* two-level forms: prims of kind 2 refer to `instances` (NULL = none) */
+void orc_intersect_closest_inst(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                                const orc_instance *instances, const orc_ray *rays, int64_t n,
+                                orc_hit *hits, int nthreads);
+void orc_intersect_any_inst(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                            const orc_instance *instances, const orc_ray *rays, int64_t n,
+                            uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests,
+                            int nthreads);
 
 /* brute force closest hit over all prims in index order (no BVH): a second,
  * tree-independent check of t for the traversal restatement. */

@@ -12,17 +12,23 @@
 // oracle/nnbvh_oracle.c and to generate tests/golden/leaf_*.bin
 // (tools/make_leaf_golden.py).  Never shipped, never on the product path.
 //
-// usage: ref_leaf <tri|blp|slab> <in.bin> <out.bin>
+//   pbrt::Transform::ApplyInverse(Ray, Float *tMax)   (src/pbrt/util/transform.h:416-429, inline:
+//                                     the interval-arithmetic ray transform TransformedPrimitive
+//                                     applies, src/pbrt/cpu/primitive.cpp:112-131)
+// usage: ref_leaf <tri|blp|slab|xfray> <in.bin> <out.bin>
 //   in.bin : int32 n, then n records of float32
 //              tri : o[3] d[3] tmax p0[3] p1[3] p2[3]              (16 floats)
 //              blp : o[3] d[3] tmax p00[3] p10[3] p01[3] p11[3]    (19 floats)
 //              slab: o[3] d[3] tmax pmin[3] pmax[3]                (13 floats)
+//              xfray: o[3] d[3] tmax m[16] mInv[16] (row-major)     (39 floats)
 //   out.bin: n records: tri  -> int32 hit, float b0 b1 b2 t
 //                       blp  -> int32 hit, float u v t
 //                       slab -> int32 hit
+//                       xfray-> int32 1, float o'[3] d'[3] tmax'
 #include <pbrt/pbrt.h>
 #include <pbrt/ray.h>
 #include <pbrt/shapes.h>
+#include <pbrt/util/transform.h>
 #include <pbrt/util/vecmath.h>
 
 #include <cstdint>
@@ -39,8 +45,9 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "usage: ref_leaf <tri|blp|slab> in.bin out.bin\n");
         return 2;
     }
-    int mode = !std::strcmp(argv[1], "tri") ? 0 : !std::strcmp(argv[1], "blp") ? 1 : 2;
-    const int stride[3] = {16, 19, 13};
+    int mode = !std::strcmp(argv[1], "tri") ? 0 : !std::strcmp(argv[1], "blp") ? 1
+               : !std::strcmp(argv[1], "slab") ? 2 : 3;
+    const int stride[4] = {16, 19, 13, 39};
     FILE *fi = std::fopen(argv[2], "rb");
     FILE *fo = std::fopen(argv[3], "wb");
     if (!fi || !fo) return 3;
@@ -53,7 +60,7 @@ int main(int argc, char **argv) {
         Ray ray(P(r), Vector3f(r[3], r[4], r[5]));
         float tMax = r[6];
         int32_t hit = 0;
-        float out[4] = {0, 0, 0, 0};
+        float out[7] = {0, 0, 0, 0, 0, 0, 0};
         int nout = 0;
         if (mode == 0) {
             auto ti = IntersectTriangle(ray, tMax, P(r + 7), P(r + 10), P(r + 13));
@@ -69,6 +76,21 @@ int main(int argc, char **argv) {
                 hit = 1;
                 out[0] = bi->uv[0], out[1] = bi->uv[1], out[2] = bi->t;
             }
+        } else if (mode == 3) {
+            SquareMatrix<4> m, mInv;
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) {
+                    m[a][b] = r[7 + 4 * a + b];
+                    mInv[a][b] = r[23 + 4 * a + b];
+                }
+            Transform xf(m, mInv);
+            Float t = tMax;
+            Ray tr = xf.ApplyInverse(ray, &t);
+            hit = 1;
+            nout = 7;
+            out[0] = tr.o.x, out[1] = tr.o.y, out[2] = tr.o.z;
+            out[3] = tr.d.x, out[4] = tr.d.y, out[5] = tr.d.z;
+            out[6] = t;
         } else {
             Bounds3f b;
             b.pMin = P(r + 7);

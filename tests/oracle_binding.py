@@ -89,3 +89,51 @@ def leaf_batch(mode, inputs):
         out = np.zeros((n, 0), np.float32)
         lib().orc_slab_batch(_p(p), _p(o), _p(d), _p(t), n, _p(hit))
     return hit, out
+
+
+INSTANCE_DTYPE = np.dtype([("m", "<f4", 12), ("m_inv", "<f4", 12), ("root", "<i4"), ("n_nodes", "<i4")])
+
+
+def apply_inverse_ray(m_inv12, o, d, tmax):
+    """orc_apply_inverse_ray on a batch: returns float32 [n, 7] = o'[3], d'[3], tmax'."""
+    mi = np.ascontiguousarray(m_inv12, np.float32).reshape(-1, 12)
+    o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(tmax, np.float32).reshape(-1)
+    out = np.zeros((len(o), 7), np.float32)
+    lib().orc_apply_inverse_ray_batch(_p(mi), _p(o), _p(d), _p(t), len(o), _p(out))
+    return out
+
+
+def transform_bounds(m12, box6):
+    out = np.zeros(6, np.float32)
+    m = np.ascontiguousarray(m12, np.float32)
+    b = np.ascontiguousarray(box6, np.float32)
+    lib().orc_transform_bounds(_p(m), _p(b), _p(out))
+    return out
+
+
+def closest_inst(nodes, prims, verts, instances, rays, nthreads=1):
+    from nn_bvh_amd._lib import HIT_DTYPE
+    nodes, prims = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+    verts = np.ascontiguousarray(verts, np.float32)
+    instances = np.ascontiguousarray(instances, INSTANCE_DTYPE)
+    rays = np.ascontiguousarray(rays)
+    hits = np.zeros(len(rays), HIT_DTYPE)
+    lib().orc_intersect_closest_inst(_p(nodes), _p(prims), _p(verts), _p(instances), _p(rays),
+                                     ctypes.c_int64(len(rays)), _p(hits), ctypes.c_int(nthreads))
+    return hits
+
+
+def any_hit_inst(nodes, prims, verts, instances, rays, nthreads=1):
+    nodes, prims = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+    verts = np.ascontiguousarray(verts, np.float32)
+    instances = np.ascontiguousarray(instances, INSTANCE_DTYPE)
+    rays = np.ascontiguousarray(rays)
+    occ = np.zeros(len(rays), np.uint8)
+    vis = np.zeros(len(rays), np.int32)
+    tst = np.zeros(len(rays), np.int32)
+    lib().orc_intersect_any_inst(_p(nodes), _p(prims), _p(verts), _p(instances), _p(rays),
+                                 ctypes.c_int64(len(rays)), _p(occ), _p(vis), _p(tst),
+                                 ctypes.c_int(nthreads))
+    return occ, vis, tst

@@ -24,6 +24,17 @@ def test_leaf_functions_match_reference_vectors_bit_exact(mode):
     assert 0.2 < h.mean() < 0.9  # both outcomes are exercised
 
 
+def test_ray_inverse_transform_matches_reference_vectors_bit_exact():
+    """Transform::ApplyInverse(Ray, tMax) (util/transform.h:416-429), the ray transform of
+    TransformedPrimitive, against vectors from the reference binary."""
+    g = np.load(os.path.join(GOLD, "leaf_xfray.npz"))
+    r = g["inputs"]
+    out = ob.apply_inverse_ray(r[:, 23:35], r[:, 0:3], r[:, 3:6], r[:, 6])
+    assert (out.view(np.uint32) == g["out_bits"]).all()
+    # the origin really moves (error-bound offset) on most inputs
+    assert (out[:, 6] != r[:, 6]).mean() > 0.2
+
+
 def test_golden_vectors_reach_the_rare_branches():
     """The vectors must include exact-zero edge functions (the fp64 fallback), degenerate
     triangles and zero direction components, or the pin would not cover those branches."""

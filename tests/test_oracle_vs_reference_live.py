@@ -98,3 +98,40 @@ def test_slab_oracle_equals_reference_on_random_inputs(seed):
     gh, _ = ob.leaf_batch("slab", recs)
     assert (gh == eh).all()
     assert 0.05 < eh.mean() < 0.95
+
+
+def random_affine(rng, n):
+    """Rotation * non-uniform scale (some negative) + translation in float64; both the matrix
+    and its float64 inverse are then rounded to float32, like a pbrt Transform's m / mInv pair."""
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                  2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).reshape(n, 3, 3)
+    S = 10.0 ** rng.uniform(-2, 2, size=(n, 3)) * rng.choice([-1, 1], size=(n, 3), p=[0.1, 0.9])
+    kind = rng.integers(0, 5, n)
+    R[kind == 0] = np.eye(3)            # pure scale + translate
+    S[kind == 1] = 1.0                  # rigid
+    M = np.zeros((n, 4, 4))
+    M[:, :3, :3] = R * S[:, None, :]
+    M[:, :3, 3] = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-1, 3, size=(n, 1))
+    M[kind == 2, :3, 3] = 0             # no translation
+    M[:, 3, 3] = 1
+    Mi = np.linalg.inv(M)
+    return M.astype(np.float32), Mi.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_ray_inverse_transform_equals_reference(seed):
+    """Transform::ApplyInverse(Ray, tMax) with its interval arithmetic (transform.h:416-429)."""
+    rng = np.random.default_rng(seed)
+    n = 20000
+    M, Mi = random_affine(rng, n)
+    o = specials(rng, (n, 3))
+    d = specials(rng, (n, 3))
+    t = np.where(rng.random(n) < 0.5, np.inf, np.abs(specials(rng, n))).astype(np.float32)
+    recs = np.concatenate([o, d, t[:, None], M.reshape(n, 16), Mi.reshape(n, 16)], 1)
+    eh, eb = run_ref("xfray", recs, 7)
+    got = ob.apply_inverse_ray(Mi.reshape(n, 16)[:, :12], o, d, t)
+    assert (got.view(np.uint32) == eb).all()

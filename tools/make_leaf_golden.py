@@ -192,12 +192,41 @@ def slab_cases(rng):
     return recs
 
 
+def xfray_cases(rng):
+    """Transform::ApplyInverse(Ray, tMax) inputs: o[3] d[3] tmax m[16] mInv[16] — rigid, scaled
+    (also mirrored), translation-free and pure-scale transforms; origins near and far."""
+    n = N
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                  2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).reshape(n, 3, 3)
+    S = 10.0 ** rng.uniform(-2, 2, size=(n, 3)) * rng.choice([-1, 1], size=(n, 3), p=[0.1, 0.9])
+    kind = rng.integers(0, 5, n)
+    R[kind == 0] = np.eye(3)
+    S[kind == 1] = 1.0
+    M = np.zeros((n, 4, 4))
+    M[:, :3, :3] = R * S[:, None, :]
+    M[:, :3, 3] = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-1, 3, size=(n, 1))
+    M[kind == 2, :3, 3] = 0
+    M[:, 3, 3] = 1
+    Mi = np.linalg.inv(M)
+    o = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-3, 4, size=(n, 1))
+    d = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-2, 2, size=(n, 1))
+    d[kind == 3, rng.integers(0, 3)] = 0.0
+    o[kind == 4] = 0.0
+    tmax = np.where(rng.random(n) < 0.5, np.inf, 10.0 ** rng.uniform(-3, 3, n))
+    return np.concatenate([o, d, tmax[:, None], M.reshape(n, 16), Mi.reshape(n, 16)], 1).astype(np.float32)
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/ref_leaf missing: run `make -C oracle ref` in the build container")
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20241008)
-    for mode, gen, nout in (("tri", tri_cases, 4), ("blp", blp_cases, 3), ("slab", slab_cases, 0)):
+    for mode, gen, nout in (("tri", tri_cases, 4), ("blp", blp_cases, 3), ("slab", slab_cases, 0),
+                            ("xfray", xfray_cases, 7)):
         recs = gen(rng)
         hit, bits = run_ref(mode, recs, nout)
         np.savez_compressed(os.path.join(OUT, f"leaf_{mode}.npz"), inputs=recs, hit=hit,
