@@ -12,17 +12,25 @@
 //                                       emitLBVH), :626-723 (buildUpperSAH over the treelets),
 //                                       util/math.h:99-119 (EncodeMorton3), :508-520 (FindInterval)
 //   DFS flattening to LinearBVHNode[]  :505-522 (flattenBVH; first child = index + 1)
-// The build is sequential, so leaf offsets are assigned in DFS order (the reference's
-// fetch_add order when no sub-tree is built in parallel, :209, :359-370); topology is
-// what the reference produces because the same libstdc++ std::partition / std::nth_element
-// are driven by the same predicates on the same float32 values.
+// Leaf offsets: a sub-tree's primitives are exactly its slice of the (recursively partitioned)
+// build array, so a leaf's firstPrimOffset is the slice's position — the DFS order the
+// reference's fetch_add gives when nothing is built in parallel (:209, :359-370) — and needs no
+// shared counter.  Like the reference (:359-370) sub-trees above 128 K primitives are built
+// by separate threads; the result does not depend on the thread count.  Topology is what
+// the reference produces because the same libstdc++ std::partition / std::nth_element are
+// driven by the same predicates on the same float32 values.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nnbvh.h"
@@ -80,28 +88,41 @@ struct BuildNode {
     int axis = 0, first = 0, n = 0;
 };
 
-struct Builder {
-    const nnbvh_prim *prims;
-    int max_prims;
-    int method;
-    std::vector<nnbvh_prim> ordered;
-    int ordered_off = 0;
-    int total_nodes = 0;
+// node storage of one build thread
+struct Arena {
     std::vector<std::unique_ptr<BuildNode[]>> pools;
     size_t pool_used = 0;
-    static constexpr size_t kPool = 1 << 16;
-
+    int count = 0;
+    static constexpr size_t kPool = 1 << 14;
     BuildNode *alloc() {
         if (pools.empty() || pool_used == kPool) {
             pools.emplace_back(new BuildNode[kPool]);
             pool_used = 0;
         }
+        ++count;
         return &pools.back()[pool_used++];
+    }
+};
+
+struct Builder {
+    const nnbvh_prim *prims;
+    int max_prims;
+    int method;
+    std::vector<nnbvh_prim> ordered;
+    const BuildPrim *bp_base = nullptr;  // start of the build array: leaf offsets are slice positions
+    int ordered_off = 0;                 // HLBVH only (sequential)
+    int total_nodes = 0;
+    Arena main_arena;
+    std::mutex mu;
+    std::vector<std::unique_ptr<Arena>> thread_arenas;
+    static constexpr size_t kParallelAbove = 128 * 1024;  // aggregates.cpp:359
+
+    BuildNode *alloc() {  // HLBVH path
+        return main_arena.alloc();
     }
 
     BuildNode *leaf(BuildNode *node, BuildPrim *bp, size_t n, const Box &bounds) {
-        int first = ordered_off;
-        ordered_off += (int)n;
+        int first = (int)(bp - bp_base);
         for (size_t i = 0; i < n; ++i) ordered[first + i] = prims[bp[i].index];
         node->first = first;
         node->n = (int)n;
@@ -109,9 +130,10 @@ struct Builder {
         return node;
     }
 
-    BuildNode *build(BuildPrim *bp, size_t n) {
-        BuildNode *node = alloc();
-        ++total_nodes;
+    BuildNode *build(BuildPrim *bp, size_t n) { return build(bp, n, main_arena); }
+
+    BuildNode *build(BuildPrim *bp, size_t n, Arena &arena) {
+        BuildNode *node = arena.alloc();
         Box bounds;
         for (size_t i = 0; i < n; ++i) bounds.add(bp[i].bounds);
         if (bounds.surface_area() == 0 || n == 1) return leaf(node, bp, n, bounds);
@@ -195,8 +217,22 @@ struct Builder {
                 }
             }
         }
-        node->child[0] = build(bp, mid);
-        node->child[1] = build(bp + mid, n - mid);
+        if (n > kParallelAbove) {
+            Arena *side;
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                thread_arenas.emplace_back(new Arena);
+                side = thread_arenas.back().get();
+            }
+            BuildNode *c0 = nullptr;
+            std::thread t([&, side] { c0 = build(bp, mid, *side); });
+            node->child[1] = build(bp + mid, n - mid, arena);
+            t.join();
+            node->child[0] = c0;
+        } else {
+            node->child[0] = build(bp, mid, arena);
+            node->child[1] = build(bp + mid, n - mid, arena);
+        }
         node->bounds = Box();
         node->bounds.add(node->child[0]->bounds);
         node->bounds.add(node->child[1]->bounds);
@@ -264,7 +300,6 @@ struct HLBuilder {
     BuildNode *emit(const MortonPrim *mp, int n, int bitIndex) {  // emitLBVH, :451-503
         if (bitIndex == -1 || n < b.max_prims) {
             BuildNode *node = b.alloc();
-            ++b.total_nodes;
             Box bounds;
             int first = b.ordered_off;
             b.ordered_off += n;
@@ -284,7 +319,6 @@ struct HLBuilder {
         });
         ++split;
         BuildNode *node = b.alloc();
-        ++b.total_nodes;
         node->child[0] = emit(mp, split, bitIndex - 1);
         node->child[1] = emit(mp + split, n - split, bitIndex - 1);
         node->bounds = Box();
@@ -300,7 +334,6 @@ struct HLBuilder {
         int n = end - start;
         if (n == 1) return roots[start];
         BuildNode *node = b.alloc();
-        ++b.total_nodes;
         Box bounds, cb;
         for (int i = start; i < end; ++i) bounds.add(roots[i]->bounds);
         for (int i = start; i < end; ++i) {
@@ -444,6 +477,9 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
         nnbvh::set_error("nnbvh_build_create: unknown split method");
         return nullptr;
     }
+    const bool timing = std::getenv("NNBVH_BUILD_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
     std::vector<BuildPrim> bp((size_t)n_prims);
     for (int i = 0; i < n_prims; ++i) {
         const nnbvh_prim &p = prims[i];
@@ -476,6 +512,7 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
     b.max_prims = std::min(255, max_prims_in_node);  // aggregates.cpp:142
     b.method = split_method;
     b.ordered.resize((size_t)n_prims);
+    auto t1 = now();
     BuildNode *root;
     if (split_method == NNBVH_SPLIT_HLBVH) {
         HLBuilder hl{b, bp, {}};
@@ -485,13 +522,22 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
             return nullptr;
         }
     } else {
+        b.bp_base = bp.data();
         root = b.build(bp.data(), bp.size());
     }
+    auto t2 = now();
     auto *out = new nnbvh_build;
+    b.total_nodes = b.main_arena.count;
+    for (auto &a : b.thread_arenas) b.total_nodes += a->count;
     out->nodes.resize((size_t)b.total_nodes);
     int off = 0;
     flatten(root, out->nodes.data(), &off, 0, &out->depth);
     out->ordered.swap(b.ordered);
+    if (timing) {
+        auto ms = [](auto a, auto c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+        std::fprintf(stderr, "nnbvh_build: bounds %.0f ms, tree %.0f ms, flatten %.0f ms\n", ms(t0, t1),
+                     ms(t1, t2), ms(t2, now()));
+    }
     return out;
 }
 
