@@ -63,3 +63,50 @@ def test_builder_under_asan_ubsan(tmp_path):
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "sanitized builder ok" in out.stdout
+
+
+TSAN_DRIVER = textwrap.dedent(r'''
+    #include <cstdio>
+    #include <cstring>
+    #include <random>
+    #include <string>
+    #include <vector>
+    #include "nnbvh.h"
+    namespace nnbvh { void set_error(const std::string &m) { std::fprintf(stderr, "err: %s\n", m.c_str()); } }
+    int main() {
+        // 300 000 primitives: above the 128 K threshold, so sub-trees are built by separate threads
+        const int n = 300000;
+        std::mt19937 rng(5);
+        std::uniform_real_distribution<float> U(-1.f, 1.f);
+        std::vector<float> verts;
+        std::vector<nnbvh_prim> prims;
+        for (int i = 0; i < n; ++i) {
+            float c[3] = {20 * U(rng), 20 * U(rng), 20 * U(rng)};
+            for (int k = 0; k < 3; ++k)
+                for (int a = 0; a < 3; ++a) verts.push_back(c[a] + 0.1f * U(rng));
+            prims.push_back(nnbvh_prim{0, i, {3 * i, 3 * i + 1, 3 * i + 2, 0}});
+        }
+        nnbvh_build *a = nnbvh_build_create(prims.data(), n, verts.data(), 3 * n, 4, NNBVH_SPLIT_SAH);
+        nnbvh_build *b = nnbvh_build_create(prims.data(), n, verts.data(), 3 * n, 4, NNBVH_SPLIT_SAH);
+        int na = 0, nb = 0;
+        const nnbvh_linear_node *A = nnbvh_build_nodes(a, &na), *B = nnbvh_build_nodes(b, &nb);
+        bool same = na == nb && !std::memcmp(A, B, sizeof(nnbvh_linear_node) * na);
+        nnbvh_build_destroy(a);
+        nnbvh_build_destroy(b);
+        std::puts(same ? "threaded builder deterministic" : "MISMATCH");
+        return same ? 0 : 1;
+    }
+''')
+
+
+def test_threaded_builder_under_tsan(tmp_path):
+    src = tmp_path / "driver.cpp"
+    src.write_text(TSAN_DRIVER)
+    exe = tmp_path / "driver"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-ffp-contract=off",
+                    "-I", os.path.join(ROOT, "include"), str(src),
+                    os.path.join(ROOT, "nn_bvh_amd", "csrc", "bvh_build.cpp"), "-o", str(exe), "-lpthread"],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "threaded builder deterministic" in out.stdout and "ThreadSanitizer" not in out.stderr
