@@ -279,3 +279,67 @@ def test_concurrent_host_threads_and_streams():
     for k in range(len(batches)):
         assert d_out[k].cpu().numpy().view(HIT_DTYPE).tobytes() == expected[k].tobytes(), f"stream {k}"
     agg.close()
+
+
+def chain_tree(depth, rng):
+    """A maximally skewed tree: every interior node has one leaf child (first) and one interior
+    child (second), `depth` edges deep — built by hand in the LinearBVHNode layout."""
+    from nn_bvh_amd import NODE_DTYPE, make_prims
+    n_leaves = depth + 1
+    x = np.arange(n_leaves, dtype=np.float32) * 2.0
+    c = np.stack([x, np.zeros_like(x), np.zeros_like(x)], 1)[:, None, :]
+    verts = (c + rng.uniform(-0.7, 0.7, size=(n_leaves, 3, 3))).reshape(-1, 3).astype(np.float32)
+    prims = make_prims(np.arange(3 * n_leaves, dtype=np.int32).reshape(n_leaves, 3))
+    nodes = np.zeros(2 * n_leaves - 1, NODE_DTYPE)
+    lo = verts.reshape(n_leaves, 3, 3).min(1)
+    hi = verts.reshape(n_leaves, 3, 3).max(1)
+    # node 2k = interior k (children: leaf 2k+1, interior/leaf 2k+2); last node = last leaf
+    for k in range(n_leaves - 1):
+        nodes[2 * k]["pmin"], nodes[2 * k]["pmax"] = lo[k:].min(0), hi[k:].max(0)
+        nodes[2 * k]["offset"], nodes[2 * k]["nprims"], nodes[2 * k]["axis"] = 2 * k + 2, 0, 0
+        nodes[2 * k + 1]["pmin"], nodes[2 * k + 1]["pmax"] = lo[k], hi[k]
+        nodes[2 * k + 1]["offset"], nodes[2 * k + 1]["nprims"] = k, 1
+    nodes[-1]["pmin"], nodes[-1]["pmax"] = lo[-1], hi[-1]
+    nodes[-1]["offset"], nodes[-1]["nprims"] = n_leaves - 1, 1
+    return verts, prims, nodes
+
+
+def test_maximum_depth_and_maximum_leaf_size():
+    """The limits of the reference's data structures: a 64-deep tree (its nodesToVisit[64],
+    aggregates.cpp:538) is accepted and exact, a deeper one is refused; a leaf with 65 535
+    primitives (uint16 nPrimitives, aggregates.cpp:511) is traversed exactly."""
+    from nn_bvh_amd import NNBVHError
+    rng = np.random.default_rng(3)
+    verts, prims, nodes = chain_tree(64, rng)
+    agg = BVHAggregate.from_tree(nodes, prims, verts)
+    assert agg.info["depth"] == 64
+    o = np.stack([np.full(3000, 140.0), rng.uniform(-0.5, 0.5, 3000), rng.uniform(-0.5, 0.5, 3000)], 1)
+    d = np.stack([-np.ones(3000), rng.uniform(-2e-3, 2e-3, 3000), rng.uniform(-2e-3, 2e-3, 3000)], 1)
+    rays = np.concatenate([make_rays(o, d), scene.random_rays(3000, verts.min(0) - 1, verts.max(0) + 1, 2)])
+    for w in (4, 8, 16):
+        agg.set_option("stack_window", w)
+        assert_hits_equal(agg.Intersect(rays), ob.closest(nodes, prims, verts, rays), f"depth 64, window {w}")
+    assert ob.closest(nodes, prims, verts, rays)["nodes_visited"].max() > 100
+    agg.close()
+    v2, p2, n2 = chain_tree(65, rng)
+    with pytest.raises(NNBVHError, match="deeper than the 64-entry"):
+        BVHAggregate.from_tree(n2, p2, v2)
+    # one leaf of 65 535 primitives
+    n = 65535
+    c = np.array([0.5, 0.5, 0.5], np.float32)
+    h = (rng.integers(1, 64, size=(n, 3)) / 128.0).astype(np.float32)
+    w3 = (rng.integers(-63, 64, size=(n, 3)) / 64.0).astype(np.float32) * h
+    verts = np.stack([c - h, c + h, c + w3], 1).reshape(-1, 3).astype(np.float32)
+    from nn_bvh_amd import make_prims
+    prims = make_prims(np.arange(3 * n, dtype=np.int32).reshape(n, 3))
+    tree = build_tree(prims, verts)
+    assert len(tree.nodes) == 1 and tree.nodes["nprims"][0] == 65535
+    rays = scene.random_rays(600, [-0.5] * 3, [1.5] * 3, 4)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+    exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, 16)
+    assert_hits_equal(agg.Intersect(rays), exp, "65535-prim leaf")
+    assert exp["prim_tests"].max() == 65535
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    eocc, evis, etst = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, 16)
+    assert (occ == eocc).all() and (tst == etst).all()
+    agg.close()
