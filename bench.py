@@ -82,10 +82,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the traversal path has no CPU fallback")
+    # NNBVH_BENCH_BACKEND=gloo (+ all ranks on the visible GPUs round-robin) is the rehearsal
+    # mode for boxes with fewer GPUs than ranks; the driver's runs use nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("NNBVH_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     from nn_bvh_amd import BVHAggregate, build_tree, make_prims, scene, shard
     from nn_bvh_amd._lib import HIT_DTYPE
@@ -156,10 +165,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([rays_per_step], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([rays_per_step], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_rays_per_step = float(tot.item())
     else:
@@ -209,17 +218,18 @@ def main():
     barrier()
     overlapped_s = time.perf_counter() - t1
     if world > 1:
-        t = torch.tensor([overlapped_s], dtype=torch.float64, device="cuda")
+        t = torch.tensor([overlapped_s], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         overlapped_s = float(t.item())
 
     allgather_ms = None
     if world > 1:
         # film-sample hand-off after the pass: one RCCL all-gather of the per-tile hit records
-        shard.all_gather_records(d_hits, shard_bytes)  # warm-up (communicator setup)
+        g_src = d_hits if backend == "nccl" else d_hits.cpu()
+        shard.all_gather_records(g_src, shard_bytes)  # warm-up (communicator setup)
         barrier()
         t1 = time.perf_counter()
-        gathered = shard.all_gather_records(d_hits, shard_bytes)
+        gathered = shard.all_gather_records(g_src, shard_bytes)
         barrier()
         allgather_ms = (time.perf_counter() - t1) * 1e3
         assert sum(g.numel() for g in gathered) == int(shard_bytes.sum())

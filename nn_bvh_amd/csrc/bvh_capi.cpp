@@ -67,7 +67,7 @@ struct nnbvh_scene {
     int window = 8;
     int blocks_per_cu = 0;  // 0 = from the occupancy query
     int xcd_queues = 1;
-    int prim_weight = 24;
+    int prim_weight = 32;
     int refill_weight = 8;
     unsigned long long *d_stats = nullptr;  // diagnostics (NNBVH_STATS builds)
     int prefetch = 0;
