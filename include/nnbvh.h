@@ -179,8 +179,7 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
  * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "prim_weight" / "refill_weight" (1..64:
  * how much a lane waiting on a primitive test / an idle lane counts against a lane waiting on
  * an interior node, which counts 16, when a wavefront picks its next step), "int_repeat" (1..16 interior steps per scheduling
- * decision), "prefetch" (0 = never, 1 = always, 2 = only while a launch
- * drains: touch the children's cache lines ahead of use).  Returns
+ * decision).  Returns
  * NNBVH_ERR_ARG for unknown keys. */
 int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value);
 

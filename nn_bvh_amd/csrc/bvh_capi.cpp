@@ -70,7 +70,6 @@ struct nnbvh_scene {
     int prim_weight = 32;
     int refill_weight = 8;
     unsigned long long *d_stats = nullptr;  // diagnostics (NNBVH_STATS builds)
-    int prefetch = 0;
     int instanced = 0;      // two-level scene: use the INST kernels
     int int_repeat = 3;
     int max_grid_threads = 0;
@@ -354,7 +353,6 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     if (const char *e = std::getenv("NNBVH_BLOCKS_PER_CU")) nnbvh_scene_set_option(s, "blocks_per_cu", atoi(e));
     if (const char *e = std::getenv("NNBVH_XCD_QUEUES")) nnbvh_scene_set_option(s, "xcd_queues", atoi(e));
     if (const char *e = std::getenv("NNBVH_REFILL_WEIGHT")) nnbvh_scene_set_option(s, "refill_weight", atoi(e));
-    if (const char *e = std::getenv("NNBVH_PREFETCH")) nnbvh_scene_set_option(s, "prefetch", atoi(e));
     if (const char *e = std::getenv("NNBVH_PRIM_WEIGHT")) nnbvh_scene_set_option(s, "prim_weight", atoi(e));
     return s;
 }
@@ -433,7 +431,7 @@ static int grid_blocks(nnbvh_scene *s, int mode) {
     if (per_cu <= 0) {
         TraceParams dummy{};
         int occ = 0;
-        if (launch_trace(mode, dummy, s->window, s->prefetch, s->instanced, 0, nullptr, &occ) != hipSuccess ||
+        if (launch_trace(mode, dummy, s->window, s->instanced, 0, nullptr, &occ) != hipSuccess ||
             occ <= 0)
             occ = std::max(1, std::min(8, 160 / (s->window * 2)));
         per_cu = occ;
@@ -498,12 +496,6 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
             return NNBVH_ERR_ARG;
         }
         s->int_repeat = value;
-    } else if (k == "prefetch") {
-        if (value < 0 || value > 2) {
-            set_error("set_option: prefetch must be 0, 1 or 2");
-            return NNBVH_ERR_ARG;
-        }
-        s->prefetch = value;
     } else if (k == "xcd_queues") {
         s->xcd_queues = value ? 1 : 0;
     } else if (k == "prim_weight") {
@@ -573,7 +565,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     int blocks = grid_blocks(s, mode);
     const int64_t need = (n + kBlockThreads - 1) / kBlockThreads;
     if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
-    if (!hip_ok(launch_trace(mode, p, s->window, s->prefetch, s->instanced, blocks, stream, nullptr),
+    if (!hip_ok(launch_trace(mode, p, s->window, s->instanced, blocks, stream, nullptr),
                 "trace kernel launch"))
         return NNBVH_ERR_DEVICE;
     return NNBVH_OK;

@@ -33,7 +33,7 @@ struct TraceParams {
 };
 
 // occupancy != nullptr: do not launch, report resident blocks per CU of that kernel instance
-hipError_t launch_trace(int mode, const TraceParams &p, int window, int prefetch, int instanced,
-                        int blocks, hipStream_t stream, int *occupancy);
+hipError_t launch_trace(int mode, const TraceParams &p, int window, int instanced, int blocks,
+                        hipStream_t stream, int *occupancy);
 
 }  // namespace nnbvh

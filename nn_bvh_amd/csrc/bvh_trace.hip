@@ -350,10 +350,6 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 // ballots) and the lanes in that state execute it; the others idle for that trip.  A ray's
 // own sequence of steps is exactly the reference's, so results cannot depend on the policy.
 //
-// PF = 1: every interior step touches the cache lines its two children will be fetched from
-// as soon as their refs are known (speed only; compile-time so that the wait for the step's
-// own record loads does not have to cover the prefetches).  PF = 2: only once the queues are
-// exhausted, i.e. while the launch drains and each remaining ray is a bare latency chain.
 // waves/SIMD the register allocator must leave room for (measured in steady state: closest
 // hit 5 -> 6 waves is +9 %; beyond that the spills cost more than the extra waves hide)
 #ifndef NNBVH_MINW_CLOSEST
@@ -368,7 +364,7 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 // interval arithmetic, traverses the child tree ABOVE the current stack level (`floor`) and
 // returns to the outer leaf when the child is exhausted.  Compiled separately so that
 // single-level scenes pay nothing for it.
-template <int MODE, int W, int PF, int INST>
+template <int MODE, int W, int INST>
 __global__ __launch_bounds__(kBlockThreads, (INST ? 1 : (MODE == 0 ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY)))
 void trace_kernel(TraceParams p) {
     __shared__ int s_ref[kBlockThreads / 64][W][64];
@@ -414,7 +410,6 @@ void trace_kernel(TraceParams p) {
     int floor = -1;      // INST: stack level the current child traversal must not pop below
     bool found = false;  // MODE 1/2
     bool exhausted = false;
-    unsigned pf0 = 0, pf1 = 0;  // landing registers of the child-record prefetches
 
     // pop entries until one whose deferred box test passes with the current tMax
     auto pop_next = [&]() -> int {
@@ -429,13 +424,71 @@ void trace_kernel(TraceParams p) {
                 ref = (int)e.x;
                 key = __uint_as_float(e.y);
                 // complete the load inside this rare branch, so that the common path's join
-                // needs no vmcnt wait (which would also drain the in-flight prefetches)
+                // needs no vmcnt wait
                 asm volatile("" : "+v"(ref), "+v"(key));
             }
             if (MODE != 2) visited += 1;
             if (key < tMax) return ref;
         }
         return (INST && floor >= 0) ? kReturn : kDone;
+    };
+
+    // TransformedPrimitive::Intersect / IntersectP (cpu/primitive.cpp:112-131): park the outer ray
+    // in LDS, transform it into the instance's space, count and test the child root.
+    auto enter_instance = [&](int slot, unsigned flags, float4 s0, float4 s1, float4 s2) {
+        const float4 s3 = p.prims[slot + 3], s4 = p.prims[slot + 4], s5 = p.prims[slot + 5];
+        const V3 dOuter = {cold[kColdD][lane], cold[kColdD + 1][lane], cold[kColdD + 2][lane]};
+        cold[kSaveO][lane] = r.o.x;
+        cold[kSaveO + 1][lane] = r.o.y;
+        cold[kSaveO + 2][lane] = r.o.z;
+        cold[kSaveInv][lane] = r.inv.x;
+        cold[kSaveInv + 1][lane] = r.inv.y;
+        cold[kSaveInv + 2][lane] = r.inv.z;
+        cold[kSaveShear][lane] = r.sx;
+        cold[kSaveShear + 1][lane] = r.sy;
+        cold[kSaveShear + 2][lane] = r.sz;
+        cold[kSaveKz][lane] = __int_as_float(r.kz);
+        cold[kSaveTmax][lane] = tMax;
+        cold[kSaveD][lane] = dOuter.x;
+        cold[kSaveD + 1][lane] = dOuter.y;
+        cold[kSaveD + 2][lane] = dOuter.z;
+        cold[kResume][lane] = __int_as_float((flags & kPrimLast) ? kDone : ~(slot + 6));
+        cold[kCurInst][lane] = __int_as_float(__float_as_int(s0.w) + 1);
+        cold[kInnerHit][lane] = 0.0f;
+        V3 oIn, dIn;
+        apply_inverse_ray(s2, s3, s4, r.o, dOuter, tMax, oIn, dIn);
+        r.o = oIn;
+        cold[kColdD][lane] = dIn.x;
+        cold[kColdD + 1][lane] = dIn.y;
+        cold[kColdD + 2][lane] = dIn.z;
+        r.inv = {1.0f / dIn.x, 1.0f / dIn.y, 1.0f / dIn.z};
+        ray_shear(r, dIn);
+        floor = sp;
+        if (MODE != 2) visited += 1;  // the child aggregate's root
+        float tEntry;
+        const bool rootHit =
+            slab_partial(s0.x, s0.y, s0.z, s1.x, s1.y, s1.z, r, tEntry) && (tEntry < tMax);
+        cur = rootHit ? __float_as_int(s5.x) : kReturn;
+    };
+
+    // the child tree is exhausted: restore the outer ray; the inner tHit becomes the outer tMax
+    // iff a hit was accepted inside (`si = primSi; tMax = si->tHit`), then resume the outer leaf
+    auto leave_instance = [&]() {
+        const bool innerHit = cold[kInnerHit][lane] != 0.0f;
+        r.o = {cold[kSaveO][lane], cold[kSaveO + 1][lane], cold[kSaveO + 2][lane]};
+        r.inv = {cold[kSaveInv][lane], cold[kSaveInv + 1][lane], cold[kSaveInv + 2][lane]};
+        r.sx = cold[kSaveShear][lane];
+        r.sy = cold[kSaveShear + 1][lane];
+        r.sz = cold[kSaveShear + 2][lane];
+        r.kz = __float_as_int(cold[kSaveKz][lane]);
+        cold[kColdD][lane] = cold[kSaveD][lane];
+        cold[kColdD + 1][lane] = cold[kSaveD + 1][lane];
+        cold[kColdD + 2][lane] = cold[kSaveD + 2][lane];
+        if (!innerHit) tMax = cold[kSaveTmax][lane];
+        cold[kCurInst][lane] = 0.0f;
+        floor = -1;
+        const int resume = __float_as_int(cold[kResume][lane]);
+        cur = (resume == kDone) ? pop_next() : resume;
     };
 
     for (;;) {
@@ -552,131 +605,64 @@ void trace_kernel(TraceParams p) {
         if (sP > sI || nInt == 0) {
             // ---- primitive step: lanes with a pending leaf test ONE primitive -----------
             if (!isInt && !isIdle) {
-                if (INST && cur == kReturn) {
-                    // the child tree of an instance is exhausted: restore the outer ray
-                    // (TransformedPrimitive::Intersect returns; `tMax = si->tHit` if it hit)
-                    const bool innerHit = cold[kInnerHit][lane] != 0.0f;
-                    r.o = {cold[kSaveO][lane], cold[kSaveO + 1][lane], cold[kSaveO + 2][lane]};
-                    r.inv = {cold[kSaveInv][lane], cold[kSaveInv + 1][lane], cold[kSaveInv + 2][lane]};
-                    r.sx = cold[kSaveShear][lane];
-                    r.sy = cold[kSaveShear + 1][lane];
-                    r.sz = cold[kSaveShear + 2][lane];
-                    r.kz = __float_as_int(cold[kSaveKz][lane]);
-                    cold[kColdD][lane] = cold[kSaveD][lane];
-                    cold[kColdD + 1][lane] = cold[kSaveD + 1][lane];
-                    cold[kColdD + 2][lane] = cold[kSaveD + 2][lane];
-                    if (!innerHit) tMax = cold[kSaveTmax][lane];
-                    cold[kCurInst][lane] = 0.0f;
-                    floor = -1;
-                    const int resume = __float_as_int(cold[kResume][lane]);
-                    cur = (resume == kDone) ? pop_next() : resume;
-                }
-                if (cur < 0 && cur != kDone && !(INST && cur == kReturn)) {
-                const int slot = ~cur;
-                const float4 s0 = p.prims[slot], s1 = p.prims[slot + 1], s2 = p.prims[slot + 2];
-                const unsigned flags = __float_as_uint(s1.w);
-                if (INST && (flags & kPrimInstance)) {
-                    // TransformedPrimitive::Intersect / IntersectP (cpu/primitive.cpp:112-131)
-                    const float4 s3 = p.prims[slot + 3], s4 = p.prims[slot + 4], s5 = p.prims[slot + 5];
-                    const V3 dOuter = {cold[kColdD][lane], cold[kColdD + 1][lane], cold[kColdD + 2][lane]};
-                    cold[kSaveO][lane] = r.o.x;
-                    cold[kSaveO + 1][lane] = r.o.y;
-                    cold[kSaveO + 2][lane] = r.o.z;
-                    cold[kSaveInv][lane] = r.inv.x;
-                    cold[kSaveInv + 1][lane] = r.inv.y;
-                    cold[kSaveInv + 2][lane] = r.inv.z;
-                    cold[kSaveShear][lane] = r.sx;
-                    cold[kSaveShear + 1][lane] = r.sy;
-                    cold[kSaveShear + 2][lane] = r.sz;
-                    cold[kSaveKz][lane] = __int_as_float(r.kz);
-                    cold[kSaveTmax][lane] = tMax;
-                    cold[kSaveD][lane] = dOuter.x;
-                    cold[kSaveD + 1][lane] = dOuter.y;
-                    cold[kSaveD + 2][lane] = dOuter.z;
-                    cold[kResume][lane] = __int_as_float((flags & kPrimLast) ? kDone : ~(slot + 6));
-                    cold[kCurInst][lane] = __int_as_float(__float_as_int(s0.w) + 1);
-                    cold[kInnerHit][lane] = 0.0f;
-                    V3 oIn, dIn;
-                    apply_inverse_ray(s2, s3, s4, r.o, dOuter, tMax, oIn, dIn);
-                    r.o = oIn;
-                    cold[kColdD][lane] = dIn.x;
-                    cold[kColdD + 1][lane] = dIn.y;
-                    cold[kColdD + 2][lane] = dIn.z;
-                    r.inv = {1.0f / dIn.x, 1.0f / dIn.y, 1.0f / dIn.z};
-                    ray_shear(r, dIn);
-                    floor = sp;
-                    if (MODE != 2) visited += 1;  // the child aggregate's root
-                    float tEntry;
-                    const bool rootHit = slab_partial(s0.x, s0.y, s0.z, s1.x, s1.y, s1.z, r, tEntry) &&
-                                         (tEntry < tMax);
-                    cur = rootHit ? __float_as_int(s5.x) : kReturn;
-                } else {
-                tests += 1;
-                bool hit;
-                float x0, x1, x2, th;
-                int next;
-                if (!(flags & kPrimPatch)) {
-                    hit = triangle_test(r, tMax, (flags & kPrimDegenerate) != 0, {s0.x, s0.y, s0.z},
-                                        {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z}, x0, x1, x2, th);
-                    next = slot + 3;
-                } else {
-                    const float4 s3 = p.prims[slot + 3];
-                    x2 = 0.0f;
-                    const V3 rd = {cold[kColdD][lane], cold[kColdD + 1][lane], cold[kColdD + 2][lane]};
-                    hit = patch_test(r, rd, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                     {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
-                    next = slot + 4;
-                }
-                if (hit) {
-                    if (MODE == 0) {
-                        cold[kColdHit][lane] = s0.w;  // primitive id bits
-                        cold[kColdHit + 1][lane] = x0;
-                        cold[kColdHit + 2][lane] = x1;
-                        cold[kColdHit + 3][lane] = x2;
-                        tMax = th;
-                        if (INST) {
-                            cold[kHitInst][lane] = cold[kCurInst][lane];
-                            cold[kInnerHit][lane] = 1.0f;
-                        }
+                if (INST && cur == kReturn) leave_instance();
+                if (cur < 0 && cur != kDone && cur != kReturn) {
+                    const int slot = ~cur;
+                    const float4 s0 = p.prims[slot], s1 = p.prims[slot + 1], s2 = p.prims[slot + 2];
+                    const unsigned flags = __float_as_uint(s1.w);
+                    if (INST && (flags & kPrimInstance)) {
+                        enter_instance(slot, flags, s0, s1, s2);
                     } else {
-                        found = true;
+                        tests += 1;
+                        bool hit;
+                        float x0, x1, x2, th;
+                        int next;
+                        if (!(flags & kPrimPatch)) {
+                            hit = triangle_test(r, tMax, (flags & kPrimDegenerate) != 0,
+                                                {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                                {s2.x, s2.y, s2.z}, x0, x1, x2, th);
+                            next = slot + 3;
+                        } else {
+                            const float4 s3 = p.prims[slot + 3];
+                            x2 = 0.0f;
+                            const V3 rd = {cold[kColdD][lane], cold[kColdD + 1][lane],
+                                           cold[kColdD + 2][lane]};
+                            hit = patch_test(r, rd, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                             {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
+                            next = slot + 4;
+                        }
+                        if (hit) {
+                            if (MODE == 0) {
+                                cold[kColdHit][lane] = s0.w;  // primitive id bits
+                                cold[kColdHit + 1][lane] = x0;
+                                cold[kColdHit + 2][lane] = x1;
+                                cold[kColdHit + 3][lane] = x2;
+                                tMax = th;
+                                if (INST) {
+                                    cold[kHitInst][lane] = cold[kCurInst][lane];
+                                    cold[kInnerHit][lane] = 1.0f;
+                                }
+                            } else {
+                                found = true;
+                            }
+                        }
+                        if (MODE != 0 && found) cur = kDone;           // aggregates.cpp:597-602
+                        else if (flags & kPrimLast) cur = pop_next();  // leaf finished
+                        else cur = ~next;
                     }
-                }
-                if (MODE != 0 && found) cur = kDone;            // aggregates.cpp:597-602
-                else if (flags & kPrimLast) cur = pop_next();   // leaf finished
-                else cur = ~next;
-                }
                 }
             }
         } else {
             // ---- interior step(s): up to p.intRepeat in a row before the next scheduling
             // decision (lanes that leave the interior state sit the remaining ones out) -------
             for (int rep = 0; rep < p.intRepeat; ++rep) {
-            if (rep > 0 && __ballot(cur >= 0) == 0ull) break;
-            if (cur >= 0) {
-                // "use" of the words the previous interior step's prefetch loads returned: this
-                // is what keeps those loads alive in the compiled code (the values themselves
-                // are irrelevant); they landed long ago, so the wait emitted here is free
-                if (PF) asm volatile("" ::"v"(pf0), "v"(pf1));
+                if (rep > 0 && __ballot(cur >= 0) == 0ull) break;
+                if (cur < 0) continue;
                 const float4 *rec = p.wide + 4 * (long)cur;
                 const float4 q3 = rec[3];
                 const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
                 const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
                 const int axis = __float_as_int(q3.z);
-                if (PF == 1 || (PF == 2 && exhausted)) {
-                    // Touch the cache line of BOTH children's next fetch (interior record or
-                    // first primitive slot) as soon as their refs are known, before the slab
-                    // arithmetic: the near child is fetched by this lane's next step, the far
-                    // child when the near subtree is exhausted.  The values are never used.
-                    const unsigned *a0 = ref0 >= 0
-                        ? reinterpret_cast<const unsigned *>(p.wide + 4 * (long)ref0)
-                        : reinterpret_cast<const unsigned *>(p.prims + (long)~ref0);
-                    const unsigned *a1 = ref1 >= 0
-                        ? reinterpret_cast<const unsigned *>(p.wide + 4 * (long)ref1)
-                        : reinterpret_cast<const unsigned *>(p.prims + (long)~ref1);
-                    pf0 = *a0;
-                    pf1 = *a1;
-                }
                 // aggregates.cpp:562-568: near child = second child iff dirIsNeg[axis]
                 const bool swap = (axis == 0 ? r.inv.x : (axis == 1 ? r.inv.y : r.inv.z)) < 0.0f;
                 float t0, t1;
@@ -704,7 +690,6 @@ void trace_kernel(TraceParams p) {
                 if (nearE && nearT < tMax) cur = nearRef;
                 else cur = pop_next();
             }
-            }
         }
     }
 #ifdef NNBVH_STATS
@@ -714,45 +699,37 @@ void trace_kernel(TraceParams p) {
 }
 
 // ------------------------------------------------------------------------------------
-template <int MODE, int W, int PF, int INST>
+template <int MODE, int W, int INST>
 static hipError_t launch_one(const TraceParams &p, int blocks, hipStream_t stream, int *occupancy) {
     if (occupancy) {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, trace_kernel<MODE, W, PF, INST>,
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, trace_kernel<MODE, W, INST>,
                                                             kBlockThreads, 0);
     }
-    hipLaunchKernelGGL((trace_kernel<MODE, W, PF, INST>), dim3((unsigned)blocks), dim3(kBlockThreads),
-                       0, stream, p);
+    hipLaunchKernelGGL((trace_kernel<MODE, W, INST>), dim3((unsigned)blocks), dim3(kBlockThreads), 0,
+                       stream, p);
     return hipGetLastError();
 }
 
-template <int MODE, int PF>
-static hipError_t launch_window(const TraceParams &p, int window, int blocks, hipStream_t stream,
-                                int *occupancy) {
+template <int MODE>
+static hipError_t launch_mode(const TraceParams &p, int window, int instanced, int blocks,
+                              hipStream_t stream, int *occupancy) {
+    // two-level scenes: one instance of the kernel (window 8)
+    if (instanced) return launch_one<MODE, 8, 1>(p, blocks, stream, occupancy);
     switch (window) {
-    case 4: return launch_one<MODE, 4, PF, 0>(p, blocks, stream, occupancy);
-    case 8: return launch_one<MODE, 8, PF, 0>(p, blocks, stream, occupancy);
-    case 16: return launch_one<MODE, 16, PF, 0>(p, blocks, stream, occupancy);
+    case 4: return launch_one<MODE, 4, 0>(p, blocks, stream, occupancy);
+    case 8: return launch_one<MODE, 8, 0>(p, blocks, stream, occupancy);
+    case 16: return launch_one<MODE, 16, 0>(p, blocks, stream, occupancy);
     default: return hipErrorInvalidValue;
     }
 }
 
-template <int MODE>
-static hipError_t launch_mode(const TraceParams &p, int window, int prefetch, int instanced,
-                              int blocks, hipStream_t stream, int *occupancy) {
-    // two-level scenes: one instance of the kernel (window 8, no prefetch)
-    if (instanced) return launch_one<MODE, 8, 0, 1>(p, blocks, stream, occupancy);
-    if (prefetch == 1) return launch_window<MODE, 1>(p, window, blocks, stream, occupancy);
-    if (prefetch == 2) return launch_window<MODE, 2>(p, window, blocks, stream, occupancy);
-    return launch_window<MODE, 0>(p, window, blocks, stream, occupancy);
-}
-
 // occupancy != nullptr: no launch, only report resident blocks per CU for that instance
-hipError_t launch_trace(int mode, const TraceParams &p, int window, int prefetch, int instanced,
-                        int blocks, hipStream_t stream, int *occupancy) {
+hipError_t launch_trace(int mode, const TraceParams &p, int window, int instanced, int blocks,
+                        hipStream_t stream, int *occupancy) {
     switch (mode) {
-    case 0: return launch_mode<0>(p, window, prefetch, instanced, blocks, stream, occupancy);
-    case 1: return launch_mode<1>(p, window, prefetch, instanced, blocks, stream, occupancy);
-    case 2: return launch_mode<2>(p, window, prefetch, instanced, blocks, stream, occupancy);
+    case 0: return launch_mode<0>(p, window, instanced, blocks, stream, occupancy);
+    case 1: return launch_mode<1>(p, window, instanced, blocks, stream, occupancy);
+    case 2: return launch_mode<2>(p, window, instanced, blocks, stream, occupancy);
     default: return hipErrorInvalidValue;
     }
 }

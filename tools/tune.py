@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--stats", action="store_true", help="print scheduling stats (NNBVH_STATS build)")
     ap.add_argument("--xcd", default="1")
     ap.add_argument("--minwaves", default="0")
-    ap.add_argument("--prefetch", default="0")
     ap.add_argument("--intrepeat", default="1")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--repeat", type=int, default=1, help="concatenate each batch this many times")
@@ -58,7 +57,7 @@ def main():
                                     [int(x) for x in args.xcd.split(",")],
                                     [int(x) for x in args.primat.split(",")],
                                     [int(x) for x in args.minwaves.split(",")],
-                                    [int(x) for x in args.prefetch.split(",")],
+                                    [0],
                                     [int(x) for x in args.intrepeat.split(",")]))
     times = {c: {k: [] for k in d} for c in combos}
 
@@ -75,7 +74,6 @@ def main():
             agg.set_option("refill_weight", c[2])
             agg.set_option("xcd_queues", c[3])
             agg.set_option("prim_weight", c[4])
-            agg.set_option("prefetch", c[6])
             agg.set_option("int_repeat", c[7])
             for kind in d:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
