@@ -10,7 +10,7 @@
 //                                     src/pbrt/cpu/aggregates.cpp:534-535 does)
 // Built by oracle/Makefile into oracle/_ref/ref_leaf (git-ignored).  Used to validate
 // oracle/nnbvh_oracle.c and to generate tests/golden/leaf_*.bin
-// (tools/make_leaf_golden.py).  Never shipped, never on the product path.
+// (tests/golden/make_leaf_golden.py).  Never shipped, never on the product path.
 //
 //   pbrt::Transform::ApplyInverse(Ray, Float *tMax)   (src/pbrt/util/transform.h:416-429, inline:
 //                                     the interval-arithmetic ray transform TransformedPrimitive

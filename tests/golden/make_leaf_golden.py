@@ -24,7 +24,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.path.join(ROOT, "oracle", "_ref", "ref_leaf")
 OUT = os.path.join(ROOT, "tests", "golden")
 N = 8192

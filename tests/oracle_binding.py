@@ -70,7 +70,7 @@ def brute_closest(prims, verts, rays):
 
 
 def leaf_batch(mode, inputs):
-    """mode in {'tri','blp','slab'}; inputs = golden record array (see tools/make_leaf_golden.py).
+    """mode in {'tri','blp','slab'}; inputs = golden record array (see tests/golden/make_leaf_golden.py).
     Returns (hit uint8[n], out float32[n,k])."""
     r = np.ascontiguousarray(inputs, np.float32)
     n = len(r)

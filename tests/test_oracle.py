@@ -1,5 +1,5 @@
 """CPU tests of the oracle itself: pinned bit-for-bit to vectors generated from the REFERENCE's
-own compiled leaf functions (tests/golden/leaf_*.npz, tools/make_leaf_golden.py), the
+own compiled leaf functions (tests/golden/leaf_*.npz, tests/golden/make_leaf_golden.py), the
 reference's Triangle.BadCases known-answer case, and tree-independent cross-checks of the
 restated traversal loop."""
 import os

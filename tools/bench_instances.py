@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Two-level scene throughput: N placements of one loop-subdivided killeroo (33 264 triangles,
 data/killeroos.npz) on a grid + a ground quad at the top level; closest-hit over a camera
-batch, INST kernels vs the oracle on a sample."""
+batch with the INST kernels (parity of this path is tests/test_instancing.py's job)."""
 import os
 import sys
 import time
@@ -10,9 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
-import oracle_binding as ob  # noqa: E402
 from nn_bvh_amd import BVHAggregate, HIT_DTYPE, instancing, make_prims, scene  # noqa: E402
 
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 20
@@ -60,9 +58,6 @@ for it in range(6):
     if it:
         ts.append(a.elapsed_time(b))
 hits = d_h.cpu().numpy().view(HIT_DTYPE)
-sel = np.random.default_rng(0).choice(len(rays), 100000, replace=False)
-exp = ob.closest_inst(nodes, prims, allv, instances, rays[sel], 16)
 print(f"closest hit: {len(rays) / np.median(ts) / 1e3:.1f} Mray/s ({np.median(ts):.2f} ms for {len(rays)} rays); "
       f"hit {np.mean(hits['prim'] >= 0):.2f}, in instances {np.mean(hits['instance'] > 0):.2f}, "
-      f"V {hits['nodes_visited'].mean():.1f}, T {hits['prim_tests'].mean():.2f}; "
-      f"sample of 100000 identical to oracle: {exp.tobytes() == hits[sel].tobytes()}")
+      f"V {hits['nodes_visited'].mean():.1f}, T {hits['prim_tests'].mean():.2f}")
