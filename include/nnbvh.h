@@ -49,6 +49,12 @@ typedef struct nnbvh_linear_node {
 
 #define NNBVH_PRIM_TRIANGLE 0       /* Triangle      (shapes.h:833-1192) */
 #define NNBVH_PRIM_BILINEAR_PATCH 1 /* BilinearPatch (shapes.h:1350-1539): v = p00,p10,p01,p11 */
+#define NNBVH_PRIM_HOST 3           /* a primitive only the host can intersect (Sphere, Disk, Cylinder,
+                                       Curve, alpha-tested GeometricPrimitive: shapes.h, cpu/
+                                       primitive.cpp:57-84): carries bounds only.  A ray that
+                                       reaches one gets hit.instance = -1 (closest) or
+                                       occluded = 2 unless a GPU primitive already occludes it
+                                       (any): the caller re-traces exactly those rays on the CPU */
 #define NNBVH_PRIM_INSTANCE 2       /* TransformedPrimitive (cpu/primitive.h:83-101): v[0] = index
                                        into the instance table; top-level tree only */
 
@@ -78,7 +84,8 @@ typedef struct nnbvh_hit {
     float b0, b1, b2; /* triangle barycentrics; patch: b0 = u, b1 = v, b2 = 0 */
     int32_t nodes_visited;
     int32_t prim_tests;
-    int32_t instance; /* 0: hit in the top-level tree (or miss); k + 1: inside instance k, and
+    int32_t instance; /* -1: the ray reached a host-only primitive: record void, re-trace on the CPU;
+                         0: hit in the top-level tree (or miss); k + 1: inside instance k, and
                          then `prim` is the child tree's primitive id and t, b* are those of the
                          instance-space ray, exactly what TransformedPrimitive::Intersect returns */
 } nnbvh_hit;
@@ -108,8 +115,8 @@ int nnbvh_device_count(void);
 #define NNBVH_SPLIT_EQUAL_COUNTS 3
 nnbvh_build *nnbvh_build_create(const nnbvh_prim *prims, int n_prims, const float *verts,
                                 int n_verts, int max_prims_in_node, int split_method);
-/* same, for a primitive list that contains NNBVH_PRIM_INSTANCE entries: prim_bounds holds
- * 6 floats (min, max) per primitive and is read for the instance entries */
+/* same, for a primitive list that contains NNBVH_PRIM_INSTANCE / NNBVH_PRIM_HOST entries:
+ * prim_bounds holds 6 floats (min, max) per primitive and is read for those entries */
 nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims,
                                             const float *verts, int n_verts,
                                             const float *prim_bounds, int max_prims_in_node,

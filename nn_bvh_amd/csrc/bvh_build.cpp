@@ -485,10 +485,11 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
         const nnbvh_prim &p = prims[i];
         int nv = p.kind == NNBVH_PRIM_TRIANGLE ? 3 : p.kind == NNBVH_PRIM_BILINEAR_PATCH ? 4 : 0;
         bp[i].index = (size_t)i;
-        if (p.kind == NNBVH_PRIM_INSTANCE) {
-            // TransformedPrimitive::Bounds() = renderFromPrimitive(child bounds), supplied
+        if (p.kind == NNBVH_PRIM_INSTANCE || p.kind == NNBVH_PRIM_HOST) {
+            // TransformedPrimitive::Bounds() = renderFromPrimitive(child bounds) / the host
+            // shape's own Bounds(): supplied by the caller
             if (!prim_bounds) {
-                nnbvh::set_error("nnbvh_build_create: instance primitives need prim_bounds");
+                nnbvh::set_error("nnbvh_build_create: instance / host primitives need prim_bounds");
                 return nullptr;
             }
             bp[i].bounds.add(prim_bounds + 6 * (size_t)i);

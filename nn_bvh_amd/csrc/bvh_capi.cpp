@@ -71,6 +71,7 @@ struct nnbvh_scene {
     int refill_weight = 8;
     unsigned long long *d_stats = nullptr;  // diagnostics (NNBVH_STATS builds)
     int instanced = 0;      // two-level scene: use the INST kernels
+    int has_host_prims = 0;
     int int_repeat = 3;
     int max_grid_threads = 0;
     std::mutex mu;
@@ -233,7 +234,10 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
         int nv, nslots;
         if (p.kind == NNBVH_PRIM_TRIANGLE) nv = nslots = 3;
         else if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) nv = nslots = 4;
-        else if (p.kind == NNBVH_PRIM_INSTANCE) {
+        else if (p.kind == NNBVH_PRIM_HOST) {
+            nv = 0;
+            nslots = 3;
+        } else if (p.kind == NNBVH_PRIM_INSTANCE) {
             nv = 0;
             nslots = 6;
             if (p.v[0] < 0 || p.v[0] >= n_instances) {
@@ -266,6 +270,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
                                     : (int32_t) ~(uint32_t)slot_of[(size_t)nodes[i].offset];
     };
     std::vector<float> stream((size_t)n_slots * 4, 0.0f);
+    bool has_host = false;
     for (int k = 0; k < n_prims; ++k) {
         const nnbvh_prim &p = prims[k];
         float *s = &stream[(size_t)slot_of[(size_t)k] * 4];
@@ -281,6 +286,13 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
             std::memcpy(&s[8], in.prim_from_render, 48);
             const int32_t rref = ref_of(in.root);
             std::memcpy(&s[20], &rref, 4);
+            continue;
+        }
+        if (p.kind == NNBVH_PRIM_HOST) {
+            flags |= kPrimHost;
+            has_host = true;
+            std::memcpy(&s[3], &p.id, 4);
+            std::memcpy(&s[7], &flags, 4);
             continue;
         }
         const int nv = p.kind == NNBVH_PRIM_TRIANGLE ? 3 : 4;
@@ -330,6 +342,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     std::memcpy(s->bounds + 3, nodes[0].pmax, 12);
     s->root_ref = ref_of(0);
     s->instanced = n_instances > 0 ? 1 : 0;
+    s->has_host_prims = has_host ? 1 : 0;
     s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
     const size_t wide_bytes = wide.size() * sizeof(WideNode);
     const size_t prim_bytes = std::max<size_t>((size_t)n_slots, 1) * 16;
@@ -556,6 +569,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     p.refillWeight = s->refill_weight;
     p.stats = s->d_stats;
     p.intRepeat = s->int_repeat;
+    p.hasHostPrims = s->has_host_prims;
     p.spill = w->spill;
     if (!hip_ok(hipMemsetAsync(w->queue, 0, kMaxQueues * kQueueStrideWords * sizeof(unsigned),
                                stream),

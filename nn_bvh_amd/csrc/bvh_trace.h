@@ -27,6 +27,7 @@ struct TraceParams {
     int nQueues;
     int primWeight;         // scheduling weight of a lane waiting on a primitive (interior = 16)
     int refillWeight;       // scheduling weight of an idle lane (interior = 16)
+    int hasHostPrims;       // scene contains NNBVH_PRIM_HOST primitives
     int intRepeat;          // interior steps per scheduling decision (>= 1)
     unsigned long long *stats;  // NNBVH_STATS builds: trips/lanes per step kind; else unused
     uint2 *spill;           // [kMaxStack][grid threads] overflow of the LDS stack window

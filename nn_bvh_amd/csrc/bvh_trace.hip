@@ -373,7 +373,8 @@ void trace_kernel(TraceParams p) {
     // ray index (read when the ray retires), the direction (read by the patch test only; the
     // triangle test uses the precomputed shear) and, closest hit, the current best hit
     // (written on an accepted hit, read at retire).  Frees 4 / 8 registers per lane.
-    constexpr int kColdRi = 0, kColdD = 1, kColdHit = 4, kColdBase = (MODE == 0) ? 8 : 4;
+    constexpr int kColdRi = 0, kColdD = 1, kColdHit = 4, kColdHost = (MODE == 0) ? 8 : 4;
+    constexpr int kColdBase = kColdHost + 1;  // kColdHost: the ray reached a host-only primitive
     // two-level scenes: the outer ray saved while a child tree is traversed
     constexpr int kSaveO = kColdBase, kSaveInv = kColdBase + 3, kSaveShear = kColdBase + 6,
                   kSaveKz = kColdBase + 9, kSaveTmax = kColdBase + 10, kSaveD = kColdBase + 11,
@@ -531,11 +532,13 @@ void trace_kernel(TraceParams p) {
                     h1.y = __int_as_float(visited);
                     h1.z = __int_as_float(tests);
                     h1.w = INST ? cold[kHitInst][lane] : 0.0f;  // 0 / instance index + 1 (bit pattern)
+                    if (p.hasHostPrims && cold[kColdHost][lane] != 0.0f) h1.w = __int_as_float(-1);
                     float4 *out = reinterpret_cast<float4 *>(p.hits) + 2 * (long)ri;
                     out[0] = h0;
                     out[1] = h1;
                 } else {
-                    p.occluded[ri] = found ? 1 : 0;
+                    const bool needHost = p.hasHostPrims && cold[kColdHost][lane] != 0.0f;
+                    p.occluded[ri] = found ? 1 : (needHost ? 2 : 0);
                     if (MODE == 1) {
                         if (p.visitedOut) p.visitedOut[ri] = visited;
                         if (p.testsOut) p.testsOut[ri] = tests;
@@ -588,6 +591,7 @@ void trace_kernel(TraceParams p) {
                     cold[kCurInst][lane] = 0.0f;
                     floor = -1;
                 }
+                if (p.hasHostPrims) cold[kColdHost][lane] = 0.0f;
                 visited = 1;  // the root
                 tests = 0;
                 found = false;
@@ -612,6 +616,11 @@ void trace_kernel(TraceParams p) {
                     const unsigned flags = __float_as_uint(s1.w);
                     if (INST && (flags & kPrimInstance)) {
                         enter_instance(slot, flags, s0, s1, s2);
+                    } else if (flags & kPrimHost) {
+                        // a primitive only the host can intersect (quadric, curve, alpha-tested
+                        // ...): this ray's result is void and the caller re-traces it on the CPU
+                        cold[kColdHost][lane] = 1.0f;
+                        cur = (flags & kPrimLast) ? pop_next() : ~(slot + 3);
                     } else {
                         tests += 1;
                         bool hit;

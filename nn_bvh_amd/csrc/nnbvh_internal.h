@@ -40,6 +40,8 @@ constexpr uint32_t kPrimDegenerate = 4u;
 //   {mInv row 0} {mInv row 1} {mInv row 2}  (renderFromPrimitive inverse, 3x4)
 //   {child root ref, 0, 0, 0}
 constexpr uint32_t kPrimInstance = 8u;
+// host-only primitive (3 slots, no geometry): {0,0,0,id} {0,0,0,flags} {0,0,0,0}
+constexpr uint32_t kPrimHost = 16u;
 
 constexpr int kMaxStack = 64;  // the reference's nodesToVisit[64], aggregates.cpp:538
 

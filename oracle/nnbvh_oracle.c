@@ -467,7 +467,7 @@ static inline int prim_test(const orc_prim *p, const float *verts, const float o
 static void closest_tree(const orc_node *nodes, const orc_prim *prims, const float *verts,
                          const orc_instance *instances, int root, const float o[3],
                          const float d[3], float *tmax_io, orc_hit *hit, int *visited_io,
-                         int *tests_io, int instance_tag) {
+                         int *tests_io, int instance_tag, int *host_io) {
     float tmax = *tmax_io;
     float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
     int neg[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
@@ -481,6 +481,10 @@ static void closest_tree(const orc_node *nodes, const orc_prim *prims, const flo
                 for (int i = 0; i < nd->nprims; ++i) {
                     const orc_prim *p = &prims[nd->offset + i];
                     float r[4];
+                    if (p->kind == 3) { /* host-only primitive: the ray's record is void */
+                        *host_io = 1;
+                        continue;
+                    }
                     if (p->kind == 2) { /* TransformedPrimitive::Intersect */
                         const orc_instance *in = &instances[p->v[0]];
                         float x[7];
@@ -489,7 +493,7 @@ static void closest_tree(const orc_node *nodes, const orc_prim *prims, const flo
                         orc_hit inner = *hit;
                         inner.prim = -1;
                         closest_tree(nodes, prims, verts, instances, in->root, x, x + 3,
-                                     &inner_tmax, &inner, &visited, &tests, p->v[0] + 1);
+                                     &inner_tmax, &inner, &visited, &tests, p->v[0] + 1, host_io);
                         if (inner.prim >= 0) { /* si = primSi; tMax = si->tHit */
                             *hit = inner;
                             tmax = inner.t;
@@ -536,8 +540,11 @@ static void closest_one(const orc_node *nodes, const orc_prim *prims, const floa
     hit->t = tmax;
     hit->b0 = hit->b1 = hit->b2 = 0.0f;
     hit->instance = 0;
-    closest_tree(nodes, prims, verts, instances, 0, ray->o, ray->d, &tmax, hit, &visited, &tests, 0);
+    int host = 0;
+    closest_tree(nodes, prims, verts, instances, 0, ray->o, ray->d, &tmax, hit, &visited, &tests, 0,
+                 &host);
     if (hit->prim < 0) hit->t = ray->tmax;
+    if (host) hit->instance = -1; /* reached a host-only primitive: record void (nnbvh.h) */
     hit->nodes_visited = visited;
     hit->prim_tests = tests;
 }
@@ -545,7 +552,7 @@ static void closest_one(const orc_node *nodes, const orc_prim *prims, const floa
 /* ---- BVHAggregate::IntersectP, aggregates.cpp:581-624 ------------------------------- */
 static int any_tree(const orc_node *nodes, const orc_prim *prims, const float *verts,
                     const orc_instance *instances, int root, const float o[3], const float d[3],
-                    float tmax, int *visited_io, int *tests_io) {
+                    float tmax, int *visited_io, int *tests_io, int *host_io) {
     float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
     int neg[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
     int to_visit = 0, cur = root, visited = *visited_io, tests = *tests_io, found = 0;
@@ -558,12 +565,16 @@ static int any_tree(const orc_node *nodes, const orc_prim *prims, const float *v
                 for (int i = 0; i < nd->nprims; ++i) {
                     const orc_prim *p = &prims[nd->offset + i];
                     float r[4];
+                    if (p->kind == 3) {
+                        *host_io = 1;
+                        continue;
+                    }
                     if (p->kind == 2) { /* TransformedPrimitive::IntersectP, primitive.cpp:128-131 */
                         const orc_instance *in = &instances[p->v[0]];
                         float x[7];
                         orc_apply_inverse_ray(in->m_inv, o, d, tmax, x);
                         if (any_tree(nodes, prims, verts, instances, in->root, x, x + 3, x[6],
-                                     &visited, &tests)) {
+                                     &visited, &tests, host_io)) {
                             found = 1;
                             goto done;
                         }
@@ -600,12 +611,12 @@ done:
 static int any_one(const orc_node *nodes, const orc_prim *prims, const float *verts,
                    const orc_instance *instances, const orc_ray *ray, int *visited_out,
                    int *tests_out) {
-    int visited = 0, tests = 0;
+    int visited = 0, tests = 0, host = 0;
     int found = any_tree(nodes, prims, verts, instances, 0, ray->o, ray->d, ray->tmax, &visited,
-                         &tests);
+                         &tests, &host);
     *visited_out = visited;
     *tests_out = tests;
-    return found;
+    return found ? 1 : (host ? 2 : 0); /* 2: unknown, a host-only primitive was reached */
 }
 
 /* ---- batch drivers (pthread fan-out mirrors ParallelFor chunking, util/parallel.cpp:291-299) */

@@ -32,7 +32,7 @@ typedef struct {
  * Triangle{meshIndex,triIndex} / BilinearPatch{meshIndex,blpIndex} handle
  * (shapes.h:1188, 1535) flattened to global vertex indices. */
 typedef struct {
-    int32_t kind; /* 0 = triangle (v[0..2]), 1 = bilinear patch (v = p00,p10,p01,p11), 2 = instance (v[0]) */
+    int32_t kind; /* 0 = triangle (v[0..2]), 1 = bilinear patch (v = p00,p10,p01,p11), 2 = instance (v[0]), 3 = host-only */
     int32_t id;   /* caller's original primitive index, returned on a hit */
     int32_t v[4];
 } orc_prim;
@@ -59,7 +59,8 @@ typedef struct {
     float b0, b1, b2; /* triangle: barycentrics; patch: b0=u, b1=v, b2=0 */
     int32_t nodes_visited;
     int32_t prim_tests;
-    int32_t instance; /* 0 = hit in the top level (or miss); k+1 = hit inside instance k */
+    int32_t instance; /* -1 = reached a host-only primitive (record void); 0 = hit in the top level
+                         (or miss); k+1 = hit inside instance k */
 } orc_hit;
 
 /* leaf tests and slab test on single inputs (return 1 = hit) */

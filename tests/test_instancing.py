@@ -114,3 +114,51 @@ def test_gpu_two_level_parity(seed):
     assert (occ == eocc).all() and (vis == evis).all() and (tst == etst).all()
     assert (agg.IntersectP(rays) == eocc).all()
     agg.close()
+
+
+def host_prim_scene(seed=0):
+    """A soup in which every 7th primitive is declared host-only (bounds only)."""
+    verts, prims = ss.random_soup(1500, 0, seed)
+    prims = prims.copy()
+    host = np.arange(len(prims)) % 7 == 3
+    tri = verts[prims["v"][:, :3]]
+    bounds = np.concatenate([tri.min(1), tri.max(1)], 1).astype(np.float32)
+    prims["kind"][host] = 3
+    tree = build_tree(prims, verts, prim_bounds=bounds)
+    return verts, tree, host
+
+
+def test_host_only_primitives_flag_rays_on_the_oracle(nnbvh_lib):
+    verts, tree, host = host_prim_scene(2)
+    rays = scene.random_rays(5000, verts.min(0), verts.max(0), 3)
+    h = ob.closest_inst(tree.nodes, tree.ordered_prims, verts, np.zeros(0, ob.INSTANCE_DTYPE), rays)
+    flagged = h["instance"] == -1
+    assert 0.05 < flagged.mean() < 0.95
+    # rays that never reach a host-only primitive are exactly the rays of the scene without them
+    keep = tree.ordered_prims["kind"] != 3
+    v2, p2 = verts, tree.ordered_prims[keep]
+    t2 = build_tree(p2, v2)
+    h2 = ob.closest(t2.nodes, t2.ordered_prims, v2, rays)
+    ok = ~flagged & (rays["d"] != 0).all(1)
+    assert (h["t"][ok].view(np.uint32) == h2["t"][ok].view(np.uint32)).all()
+    assert not np.isin(h["prim"][h["prim"] >= 0], np.nonzero(host)[0]).any()  # never "hit"
+
+
+@pytest.mark.gpu
+def test_gpu_host_only_primitives_parity():
+    from test_gpu_parity import assert_hits_equal
+    verts, tree, host = host_prim_scene(4)
+    rays = np.concatenate([scene.random_rays(20000, verts.min(0), verts.max(0), 5),
+                           scene.random_rays(5000, verts.min(0), verts.max(0), 6, tmax=np.float32(1 - 1e-4))])
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+    none = np.zeros(0, ob.INSTANCE_DTYPE)
+    exp = ob.closest_inst(tree.nodes, tree.ordered_prims, verts, none, rays, 16)
+    got = agg.Intersect(rays)
+    assert_hits_equal(got, exp, "host prims closest")
+    assert (got["instance"] == exp["instance"]).all() and (exp["instance"] == -1).mean() > 0.05
+    eocc, evis, etst = ob.any_hit_inst(tree.nodes, tree.ordered_prims, verts, none, rays, 16)
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    assert (occ == eocc).all() and (vis == evis).all() and (tst == etst).all()
+    assert set(np.unique(eocc)) == {0, 1, 2}
+    assert (agg.IntersectP(rays) == eocc).all()
+    agg.close()
