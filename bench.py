@@ -67,6 +67,10 @@ def main():
                     help="tree builder: pbrt split methods, or nn = greedy-SAH top levels of "
                          "machine_learning/nn_BVH.py finished by SAH and baked (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlapped", action="store_true",
+                    help="also time the step as one nnbvh_trace_batches_device call (concurrent "
+                         "launches; off by default so that a rocprofv3 kernel average of this "
+                         "command equals roofline.avg_launch_ms)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="rays per class timed on the host cores for cpu_baseline")
     ap.add_argument("--cpu-passes", type=int, default=5)
@@ -210,14 +214,16 @@ def main():
                                   ("closest", d_bounce.data_ptr(), len(bounce), d_bhits.data_ptr()),
                                   ("any", d_shadow.data_ptr(), len(shadow), d_occ.data_ptr())], stream)
 
-    step_overlapped()
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
+    overlapped_s = None
+    if args.overlapped:
         step_overlapped()
-    barrier()
-    overlapped_s = time.perf_counter() - t1
-    if world > 1:
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_overlapped()
+        barrier()
+        overlapped_s = time.perf_counter() - t1
+    if world > 1 and overlapped_s is not None:
         t = torch.tensor([overlapped_s], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         overlapped_s = float(t.item())
@@ -294,12 +300,13 @@ def main():
                 "avg_launch_ms": round(ms_closest / 2, 4),
             },
         }
-        result["overlapped_batches"] = {
-            "value": round(total_rays_per_step * args.steps / overlapped_s / 1e6, 2),
-            "unit": "Mray/s",
-            "ms_per_step": round(overlapped_s / args.steps * 1e3, 4),
-            "how": "same step as one nnbvh_trace_batches_device call (3 batches concurrent)",
-        }
+        if overlapped_s is not None:
+            result["overlapped_batches"] = {
+                "value": round(total_rays_per_step * args.steps / overlapped_s / 1e6, 2),
+                "unit": "Mray/s",
+                "ms_per_step": round(overlapped_s / args.steps * 1e3, 4),
+                "how": "same step as one nnbvh_trace_batches_device call (3 batches concurrent)",
+            }
         if allgather_ms is not None:
             result["allgather_ms"] = round(allgather_ms, 3)
 
