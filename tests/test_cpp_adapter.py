@@ -28,3 +28,30 @@ def test_adapter_per_ray_and_batched_agree(nnbvh_lib):
     out = subprocess.run([EXE], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "adapter ok" in out.stdout
+
+
+C_DEMO = os.path.join(ROOT, "examples", "trace_demo")
+
+
+def _build_c_demo():
+    libdir = os.path.join(ROOT, "nn_bvh_amd")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "trace_demo.c"), "-o", C_DEMO, "-L", libdir,
+                    "-l:libnnbvh_hip.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib", "-lm"],
+                   check=True)
+
+
+def test_header_is_plain_c_and_demo_builds(nnbvh_lib):
+    """include/nnbvh.h must compile as C11 (the ABI claim), and the pure-C example must link."""
+    _build_c_demo()
+    out = subprocess.run([C_DEMO], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "2048 triangles" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_demo_traces_on_gpu(nnbvh_lib):
+    _build_c_demo()
+    out = subprocess.run([C_DEMO], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ray 0: prim" in out.stdout and "t 5" in out.stdout
