@@ -143,8 +143,12 @@ def main():
     hits = d_hits.cpu().numpy().view(HIT_DTYPE)
     bounce = scene.bounce_rays(primary, hits, verts, tris, seed=2 + rank)
     lo, hi = verts.min(0), verts.max(0)
-    shadow = scene.shadow_rays(primary, hits, verts, tris, lo + (hi - lo) * [0.3, 0.9, 0.3],
-                               lo + (hi - lo) * [0.7, 1.0, 0.7], seed=3 + rank)
+    if args.scene == "crown":  # towards the scene's six area-light quads (crown.pbrt:26-102)
+        shadow = scene.shadow_rays_to_quads(primary, hits, verts, tris, scene.CROWN_LIGHT_QUADS,
+                                            seed=3 + rank)
+    else:
+        shadow = scene.shadow_rays(primary, hits, verts, tris, lo + (hi - lo) * [0.3, 0.9, 0.3],
+                                   lo + (hi - lo) * [0.7, 1.0, 0.7], seed=3 + rank)
     d_bounce, d_shadow = dev(bounce), dev(shadow)
     d_bhits = torch.empty(len(bounce) * 32, dtype=torch.uint8, device="cuda")
     d_occ = torch.empty(len(shadow), dtype=torch.uint8, device="cuda")

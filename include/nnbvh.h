@@ -14,6 +14,8 @@
  *                              like CPUAggregate::IntersectClosest (wavefront/aggregate.cpp:34-58)
  *   nnbvh_intersect_any     <- BVHAggregate::IntersectP()      (cpu/aggregates.cpp:581-624), batched
  *                              like CPUAggregate::IntersectShadow  (wavefront/aggregate.cpp:60-68)
+ *   nnbvh_wavefront_*       <- WavefrontAggregate::IntersectClosest / IntersectShadow incl. the
+ *                              queue push rules (wavefront/integrator.h:32-54, intersect.h:16-156)
  *   nnbvh_build_*           <- BVHAggregate ctor + buildRecursive + flattenBVH
  *                              (cpu/aggregates.cpp:140-387, 505-522); host-side, no GPU needed
  *
@@ -181,6 +183,63 @@ typedef struct nnbvh_batch {
 } nnbvh_batch;
 int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n_batches,
                                void *stream);
+
+/* ---- wavefront queues: WavefrontAggregate::IntersectClosest / IntersectShadow ---------------
+ * (wavefront/integrator.h:32-54; CPU implementation wavefront/aggregate.cpp:34-68).  The ray
+ * queue arrives in the reference's SOA layout, its size may live on the device (the reference's
+ * WorkQueue::size is read by the kernels, workqueue.h:54-63, 143-152), and the calls apply the
+ * reference's enqueue rules (wavefront/intersect.h:16-30, 49-156) and shadow bookkeeping
+ * (intersect.h:32-47) on the device.  Output queues hold INDICES into the input queue: the
+ * caller's material / light / escape stages gather their payload (beta, lambda, pixelIndex ...)
+ * from the input work items by index, and the geometric part of the hit from d_hits[index].
+ * Not covered (they need the media / material systems, out of this path's scope):
+ * IntersectShadowTr and IntersectOneRandom (aggregate.cpp:70-116) — the reference only selects
+ * them for scenes with participating media or subsurface materials (wavefront/integrator.cpp:
+ * 91-110, 576-579). */
+typedef struct nnbvh_ray_soa {   /* SOA<Ray> slices (workitems.soa:40-50, 82-88), device pointers */
+    const float *ox, *oy, *oz;
+    const float *dx, *dy, *dz;
+    const float *time;           /* nullable */
+    const float *tmax;           /* ShadowRayWorkItem::tMax; NULL = Infinity (RayQueue) */
+    const uint8_t *has_medium;   /* nullable: ray.medium != nullptr */
+} nnbvh_ray_soa;
+
+typedef struct nnbvh_work_queue { /* WorkQueue<T> (wavefront/workqueue.h:36-113) of item indices */
+    int32_t *items;               /* device, `capacity` entries */
+    int32_t *size;                /* device counter, advanced atomically; NULL = queue not wanted */
+    int32_t capacity;             /* pushes beyond it are counted in *size but not stored */
+    int32_t pad;
+} nnbvh_work_queue;
+
+typedef struct nnbvh_closest_queues { /* the out-parameters of IntersectClosest, in its order */
+    nnbvh_work_queue escaped;                 /* EscapedRayQueue                               */
+    nnbvh_work_queue hit_area_light;          /* HitAreaLightQueue                             */
+    nnbvh_work_queue basic_eval_material;     /* MaterialEvalQueue, basic texture evaluator    */
+    nnbvh_work_queue universal_eval_material; /* MaterialEvalQueue, universal evaluator        */
+    nnbvh_work_queue medium_sample;           /* MediumSampleQueue                             */
+    nnbvh_work_queue next_ray;                /* rays continuing through an interface surface  */
+} nnbvh_closest_queues;
+
+/* per-primitive class byte, indexed by the primitive id a hit returns: what the reference reads
+ * off the hit's SurfaceInteraction when it enqueues (intersect.h:93-128) */
+#define NNBVH_CLASS_BASIC 0      /* material evaluable by BasicTextureEvaluator                */
+#define NNBVH_CLASS_UNIVERSAL 1  /* needs UniversalTextureEvaluator                           */
+#define NNBVH_CLASS_INTERFACE 2  /* no material: interface between media (intersect.h:103)    */
+#define NNBVH_CLASS_AREA_LIGHT 4 /* intr.areaLight set (intersect.h:113); combines with 0/1   */
+
+/* n = min(max_rays, *d_size) when d_size != NULL, else max_rays.  d_hits: nnbvh_hit[max_rays].
+ * d_prim_class may be NULL (every primitive NNBVH_CLASS_BASIC). */
+int nnbvh_wavefront_intersect_closest(nnbvh_scene *s, int32_t max_rays, const nnbvh_ray_soa *ray_queue,
+                                      const int32_t *d_size, const uint8_t *d_prim_class,
+                                      int64_t n_prim_class, void *d_hits,
+                                      const nnbvh_closest_queues *out, void *stream);
+/* Unoccluded rays add Ld / (r_u + r_l).Average() to d_L[4 * pixel_index] (SampledSpectrum = 4
+ * floats per item, SOA<SampledSpectrum> keeps them as one float4: util/soa.h:47-127).
+ * d_occluded: optional uint8[max_rays] copy of the per-ray result. */
+int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnbvh_ray_soa *shadow_queue,
+                                     const int32_t *d_size, const float *d_Ld, const float *d_r_u,
+                                     const float *d_r_l, const int32_t *d_pixel_index, float *d_L,
+                                     int64_t n_pixels, uint8_t *d_occluded, void *stream);
 
 /* tuning knobs (speed only, never results): "stack_window" (LDS entries per lane: 4, 8, 16),
  * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "prim_weight" / "refill_weight" (1..64:

@@ -20,7 +20,15 @@ BATCH_DTYPE = np.dtype([("kind", "<i4"), ("pad", "<i4"), ("d_rays", "<u8"), ("n"
                         ("d_out", "<u8"), ("d_nodes_visited", "<u8"), ("d_prim_tests", "<u8")])
 HIT_DTYPE = np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"),
                       ("nodes_visited", "<i4"), ("prim_tests", "<i4"), ("instance", "<i4")])
+RAY_SOA_DTYPE = np.dtype([(k, "<u8") for k in ("ox", "oy", "oz", "dx", "dy", "dz", "time", "tmax",
+                                                "has_medium")])
+WORK_QUEUE_DTYPE = np.dtype([("items", "<u8"), ("size", "<u8"), ("capacity", "<i4"), ("pad", "<i4")])
+CLOSEST_QUEUES = ("escaped", "hit_area_light", "basic_eval_material", "universal_eval_material",
+                  "medium_sample", "next_ray")
+CLOSEST_QUEUES_DTYPE = np.dtype([(k, WORK_QUEUE_DTYPE) for k in CLOSEST_QUEUES])
+CLASS_BASIC, CLASS_UNIVERSAL, CLASS_INTERFACE, CLASS_AREA_LIGHT = 0, 1, 2, 4
 assert NODE_DTYPE.itemsize == 32 and PRIM_DTYPE.itemsize == 24
+assert RAY_SOA_DTYPE.itemsize == 72 and CLOSEST_QUEUES_DTYPE.itemsize == 6 * 24
 assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 32
 
 EXPORTS = [
@@ -30,7 +38,8 @@ EXPORTS = [
     "nnbvh_intersect_closest", "nnbvh_intersect_any", "nnbvh_intersect_closest_device",
     "nnbvh_intersect_any_device", "nnbvh_scene_set_option", "nnbvh_scene_sched_stats",
     "nnbvh_trace_batches_device", "nnbvh_scene_create_instanced", "nnbvh_transform_bounds",
-    "nnbvh_build_create_with_bounds",
+    "nnbvh_build_create_with_bounds", "nnbvh_wavefront_intersect_closest",
+    "nnbvh_wavefront_intersect_shadow",
 ]
 
 _lib = None
@@ -89,6 +98,10 @@ def lib():
     L.nnbvh_build_create_with_bounds.argtypes = [vp, i32, vp, i32, vp, i32, i32]
     L.nnbvh_trace_batches_device.restype = i32
     L.nnbvh_trace_batches_device.argtypes = [vp, vp, i32, vp]
+    L.nnbvh_wavefront_intersect_closest.restype = i32
+    L.nnbvh_wavefront_intersect_closest.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp]
+    L.nnbvh_wavefront_intersect_shadow.restype = i32
+    L.nnbvh_wavefront_intersect_shadow.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
     L.nnbvh_scene_sched_stats.restype = i32
     L.nnbvh_scene_sched_stats.argtypes = [vp, vp, i32]
     _lib = L

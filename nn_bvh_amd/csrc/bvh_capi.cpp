@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "bvh_trace.h"
+#include "wavefront.h"
 
 namespace nnbvh {
 
@@ -550,7 +551,8 @@ static Workspace *workspace_for(nnbvh_scene *s, hipStream_t stream) {
 }
 
 static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void *d_hits,
-                  void *d_occ, void *d_vis, void *d_tests, hipStream_t stream, Workspace *w) {
+                  void *d_occ, void *d_vis, void *d_tests, hipStream_t stream, Workspace *w,
+                  const int32_t *d_n = nullptr) {
     TraceParams p;
     p.wide = s->d_wide;
     p.prims = s->d_prims;
@@ -563,6 +565,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     p.visitedOut = (int32_t *)d_vis;
     p.testsOut = (int32_t *)d_tests;
     p.n = (long)n;
+    p.nDev = d_n;
     p.queue = w->queue;
     p.nQueues = s->xcd_queues ? kMaxQueues : 1;
     p.primWeight = s->prim_weight;
@@ -690,6 +693,87 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
             !hip_ok(hipStreamWaitEvent(stream, s->ev_join[k], 0), "hipStreamWaitEvent(join)"))
             return NNBVH_ERR_DEVICE;
     }
+    return NNBVH_OK;
+}
+
+// ---- wavefront queues (wavefront/aggregate.cpp:34-68 on the device) ---------------------------
+static bool soa_ok(const nnbvh_ray_soa *q) {
+    return q && q->ox && q->oy && q->oz && q->dx && q->dy && q->dz;
+}
+
+int nnbvh_wavefront_intersect_closest(nnbvh_scene *s, int32_t max_rays, const nnbvh_ray_soa *ray_queue,
+                                      const int32_t *d_size, const uint8_t *d_prim_class,
+                                      int64_t n_prim_class, void *d_hits,
+                                      const nnbvh_closest_queues *out, void *stream_) {
+    if (!s || max_rays < 0 || !out || (max_rays > 0 && (!soa_ok(ray_queue) || !d_hits)) ||
+        n_prim_class < 0) {
+        set_error("wavefront_intersect_closest: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    const nnbvh_work_queue *qs[6] = {&out->escaped, &out->hit_area_light, &out->basic_eval_material,
+                                     &out->universal_eval_material, &out->medium_sample,
+                                     &out->next_ray};
+    for (const nnbvh_work_queue *q : qs)
+        if (q->size && (q->capacity < 0 || (q->capacity > 0 && !q->items))) {
+            set_error("wavefront_intersect_closest: queue with a size counter but no item storage");
+            return NNBVH_ERR_ARG;
+        }
+    if (max_rays == 0) return NNBVH_OK;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(s->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    Workspace *w = workspace_for(s, stream);
+    if (!w) return NNBVH_ERR_DEVICE;
+    if (!grow(&w->d_in, &w->in_bytes, (size_t)max_rays * sizeof(nnbvh_ray), "hipMalloc(wavefront rays)"))
+        return NNBVH_ERR_DEVICE;
+    const WavefrontCount cnt{max_rays, d_size};
+    const int max_blocks = s->n_cus * 8;
+    if (!hip_ok(launch_wf_gather(*ray_queue, cnt, w->d_in, max_blocks, stream), "gather kernel launch"))
+        return NNBVH_ERR_DEVICE;
+    const int rc = launch(s, 0, w->d_in, max_rays, d_hits, nullptr, nullptr, nullptr, stream, w, d_size);
+    if (rc != NNBVH_OK) return rc;
+    if (!hip_ok(launch_wf_enqueue_closest(d_hits, cnt, ray_queue->has_medium, d_prim_class,
+                                          (long)n_prim_class, *out, max_blocks, stream),
+                "enqueue kernel launch"))
+        return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
+}
+
+int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnbvh_ray_soa *shadow_queue,
+                                     const int32_t *d_size, const float *d_Ld, const float *d_r_u,
+                                     const float *d_r_l, const int32_t *d_pixel_index, float *d_L,
+                                     int64_t n_pixels, uint8_t *d_occluded, void *stream_) {
+    if (!s || max_rays < 0 || n_pixels < 0 ||
+        (max_rays > 0 && (!soa_ok(shadow_queue) || !d_Ld || !d_r_u || !d_r_l || !d_pixel_index || !d_L))) {
+        set_error("wavefront_intersect_shadow: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    if (max_rays == 0) return NNBVH_OK;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(s->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    Workspace *w = workspace_for(s, stream);
+    if (!w) return NNBVH_ERR_DEVICE;
+    if (!grow(&w->d_in, &w->in_bytes, (size_t)max_rays * sizeof(nnbvh_ray), "hipMalloc(wavefront rays)"))
+        return NNBVH_ERR_DEVICE;
+    uint8_t *occ = d_occluded;
+    if (!occ) {
+        if (!grow(&w->d_out, &w->out_bytes, (size_t)max_rays, "hipMalloc(wavefront occluded)"))
+            return NNBVH_ERR_DEVICE;
+        occ = (uint8_t *)w->d_out;
+    }
+    const WavefrontCount cnt{max_rays, d_size};
+    const int max_blocks = s->n_cus * 8;
+    if (!hip_ok(launch_wf_gather(*shadow_queue, cnt, w->d_in, max_blocks, stream), "gather kernel launch"))
+        return NNBVH_ERR_DEVICE;
+    const int rc = launch(s, 2, w->d_in, max_rays, nullptr, occ, nullptr, nullptr, stream, w, d_size);
+    if (rc != NNBVH_OK) return rc;
+    if (!hip_ok(launch_wf_record_shadow(occ, cnt, d_Ld, d_r_u, d_r_l, d_pixel_index, d_L, (long)n_pixels,
+                                        max_blocks, stream),
+                "shadow record kernel launch"))
+        return NNBVH_ERR_DEVICE;
     return NNBVH_OK;
 }
 

@@ -23,6 +23,7 @@ struct TraceParams {
     int32_t *visitedOut;    // MODE 1, nullable
     int32_t *testsOut;      // MODE 1, nullable
     long n;
+    const int32_t *nDev;    // nullable: device-resident batch size, clamped to [0, n]
     unsigned *queue;        // nQueues heads, kQueueStrideWords apart, zeroed before launch
     int nQueues;
     int primWeight;         // scheduling weight of a lane waiting on a primitive (interior = 16)

@@ -400,6 +400,12 @@ void trace_kernel(TraceParams p) {
         q = (int)(xcc & 0xf) % p.nQueues;
     }
     int queuesTried = 0;
+    // batch size: the host's bound, or a device-resident queue size below it (wavefront callers)
+    long nRays = p.n;
+    if (p.nDev) {
+        const long nd = (long)*p.nDev;
+        nRays = nd < 0 ? 0 : (nd < nRays ? nd : nRays);
+    }
 
 #ifdef NNBVH_STATS
     unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // trips/lanes per kind (I, P, R); [6..8] = sum nInt,nPrim,nIdle over I trips
@@ -549,7 +555,7 @@ void trace_kernel(TraceParams p) {
             if (exhausted) break;  // only reached with every lane idle (sR == 0 otherwise)
             long start = 0;
             for (;;) {  // find a queue with work left (own XCD's first, then steal)
-                const long qBegin = p.n * q / p.nQueues, qEnd = p.n * (q + 1) / p.nQueues;
+                const long qBegin = nRays * q / p.nQueues, qEnd = nRays * (q + 1) / p.nQueues;
                 unsigned got = 0;
                 if (lane == 0) got = atomicAdd(&p.queue[q * kQueueStrideWords], (unsigned)nIdle);
                 got = __builtin_amdgcn_readfirstlane(got);

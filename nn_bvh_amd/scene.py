@@ -30,6 +30,25 @@ CAMERAS = {
 }
 
 
+# The six area-light quads of the crown scene (scene description data: the "point3 P" lists of
+# /root/reference/scenes/crown/crown.pbrt:26-102; corners in the file's order).  Shadow rays of
+# the crown workload aim at uniformly sampled points on them.
+CROWN_LIGHT_QUADS = np.array([
+    [[5.702774, -13.539273, -76.185936], [-14.945709, -13.791711, -75.26613],
+     [-14.886804, 13.04458, -66.57877], [5.761684, 13.297014, -67.49859]],
+    [[41.6316, 14.548275, -16.682684], [45.396217, 14.548271, -2.696177],
+     [40.693626, 28.926506, -1.430422], [36.92901, 28.926506, -15.416933]],
+    [[-45.1155, 14.650443, -2.989656], [-41.24645, 14.65044, -16.947636],
+     [-36.506706, 29.012154, -15.633818], [-40.37576, 29.012156, -1.675834]],
+    [[20.38967, -4.332172, 17.202255], [13.206003, -4.332175, 23.926588],
+     [15.053431, 5.620016, 25.900215], [22.237099, 5.620017, 19.17588]],
+    [[-18.349361, -3.757668, 23.42476], [-24.791203, -3.75767, 15.977483],
+     [-26.581875, 6.287214, 17.5264], [-20.140032, 6.287215, 24.973679]],
+    [[9.260806, 19.171276, 24.593668], [-9.12361, 19.171274, 25.294205],
+     [-9.666298, 32.1588, 11.052294], [8.718122, 32.1588, 10.351759]],
+], np.float64)
+
+
 # ---------------------------------------------------------------------------------------
 def read_ply(path):
     """Binary-little-endian PLY with float x,y,z(+extras) vertices and uint8-counted int
@@ -282,6 +301,24 @@ def shadow_rays(rays, hits, verts, tris, light_lo, light_hi, seed=3, eps_scale=1
     rng = np.random.default_rng(seed)
     lo, hi = np.asarray(light_lo, np.float64), np.asarray(light_hi, np.float64)
     pl = lo + rng.random((len(p), 3)) * (hi - lo)
+    scale = float(np.abs(verts).max())
+    o = (p + n * eps_scale * scale).astype(np.float32)
+    out = np.zeros(len(p), RAY_DTYPE)
+    out["o"] = o
+    out["d"] = pl.astype(np.float32) - o
+    out["tmax"] = np.float32(1 - 1e-4)
+    return out
+
+
+def shadow_rays_to_quads(rays, hits, verts, tris, quads, seed=3, eps_scale=1e-4):
+    """Shadow rays from hit points to uniformly sampled points on area-light quads (corners
+    p0 p1 p2 p3 in order; the light is chosen uniformly, the point bilinearly — the quads are
+    parallelograms): un-normalised d = pLight - p, tMax = 1 - ShadowEpsilon."""
+    p, n, _ = hit_points(rays, hits, verts, tris)
+    rng = np.random.default_rng(seed)
+    q = np.asarray(quads, np.float64)[rng.integers(0, len(quads), len(p))]
+    u, v = rng.random((len(p), 1)), rng.random((len(p), 1))
+    pl = q[:, 0] + u * (q[:, 1] - q[:, 0]) + v * (q[:, 3] - q[:, 0])
     scale = float(np.abs(verts).max())
     o = (p + n * eps_scale * scale).astype(np.float32)
     out = np.zeros(len(p), RAY_DTYPE)

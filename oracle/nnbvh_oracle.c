@@ -759,3 +759,63 @@ void orc_brute_closest(const orc_prim *prims, int n_prims, const float *verts,
         h->prim_tests = n_prims;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Wavefront queue rules, restated on work-item indices.
+ *
+ * EnqueueWorkAfterMiss (wavefront/intersect.h:16-30): a missing ray with a medium goes to the
+ * medium-sample queue, otherwise to the escaped-ray queue.
+ * EnqueueWorkAfterIntersection (intersect.h:49-156): a hit ray with a medium goes to the
+ * medium-sample queue and nothing else (:56-90); otherwise a surface without material is an
+ * interface and the ray continues via nextRayQueue (:103-111); otherwise an emissive surface is
+ * also pushed to the hit-area-light queue (:113-120) and the item goes to the basic or the
+ * universal material-evaluation queue (:122-128).  cls bits: 1 = universal, 2 = interface,
+ * 4 = area light.  Queue order here is index order; the reference's is whatever its threads
+ * produce, so tests compare queue CONTENTS.
+ * queues / sizes order: escaped, hit_area_light, basic, universal, medium_sample, next_ray. */
+void orc_wavefront_enqueue_closest(const orc_hit *hits, int n, const uint8_t *has_medium,
+                                   const uint8_t *prim_class, int64_t n_class,
+                                   int32_t *const queues[6], int32_t sizes[6]) {
+    for (int k = 0; k < 6; ++k) sizes[k] = 0;
+    for (int i = 0; i < n; ++i) {
+        const int medium = has_medium && has_medium[i];
+        if (hits[i].prim < 0) {
+            const int q = medium ? 4 : 0;
+            queues[q][sizes[q]++] = i;
+            continue;
+        }
+        if (medium) {
+            queues[4][sizes[4]++] = i;
+            continue;
+        }
+        unsigned cls = 0;
+        if (prim_class && hits[i].prim < n_class) cls = prim_class[hits[i].prim];
+        if (cls & 2u) {
+            queues[5][sizes[5]++] = i;
+            continue;
+        }
+        if (cls & 4u) queues[1][sizes[1]++] = i;
+        const int q = (cls & 1u) ? 3 : 2;
+        queues[q][sizes[q]++] = i;
+    }
+}
+
+/* RecordShadowRayResult (wavefront/intersect.h:32-47) with SampledSpectrum = 4 floats
+ * (util/spectrum.h:36): Ld / (r_u + r_l).Average(), Average() = left-to-right sum / 4
+ * (spectrum.h:256-261), operator/(Float) divides each component (spectrum.h:163-174). */
+void orc_record_shadow(const uint8_t *occluded, int n, const float *Ld, const float *r_u,
+                       const float *r_l, const int32_t *pixel_index, float *L) {
+    for (int i = 0; i < n; ++i) {
+        if (occluded[i]) continue;
+        float s[4];
+        for (int c = 0; c < 4; ++c) s[c] = r_u[4 * i + c] + r_l[4 * i + c];
+        float sum = s[0];
+        for (int c = 1; c < 4; ++c) sum += s[c];
+        const float avg = sum / 4;
+        float *dst = L + 4 * (int64_t)pixel_index[i];
+        for (int c = 0; c < 4; ++c) {
+            const float ld = Ld[4 * i + c] / avg;
+            dst[c] = dst[c] + ld;
+        }
+    }
+}

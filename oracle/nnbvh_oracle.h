@@ -106,6 +106,15 @@ void orc_intersect_any_inst(const orc_node *nodes, const orc_prim *prims, const 
                             uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests,
                             int nthreads);
 
+/* wavefront queue rules (wavefront/intersect.h:16-156) on work-item indices; queues / sizes in
+ * the order escaped, hit_area_light, basic_eval, universal_eval, medium_sample, next_ray */
+void orc_wavefront_enqueue_closest(const orc_hit *hits, int n, const uint8_t *has_medium,
+                                   const uint8_t *prim_class, int64_t n_class,
+                                   int32_t *const queues[6], int32_t sizes[6]);
+/* RecordShadowRayResult (wavefront/intersect.h:32-47); Ld, r_u, r_l, L: 4 floats per item/pixel */
+void orc_record_shadow(const uint8_t *occluded, int n, const float *Ld, const float *r_u,
+                       const float *r_l, const int32_t *pixel_index, float *L);
+
 /* brute force closest hit over all prims in index order (no BVH): a second,
  * tree-independent check of t for the traversal restatement. */
 void orc_brute_closest(const orc_prim *prims, int n_prims, const float *verts,

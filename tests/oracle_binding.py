@@ -137,3 +137,28 @@ def any_hit_inst(nodes, prims, verts, instances, rays, nthreads=1):
                                  ctypes.c_int64(len(rays)), _p(occ), _p(vis), _p(tst),
                                  ctypes.c_int(nthreads))
     return occ, vis, tst
+
+
+def wavefront_enqueue_closest(hits, has_medium=None, prim_class=None):
+    """orc_wavefront_enqueue_closest: returns the six index queues (escaped, hit_area_light,
+    basic_eval, universal_eval, medium_sample, next_ray) as int32 arrays."""
+    hits = np.ascontiguousarray(hits)
+    n = len(hits)
+    hm = np.ascontiguousarray(has_medium, np.uint8) if has_medium is not None else None
+    pc = np.ascontiguousarray(prim_class, np.uint8) if prim_class is not None else None
+    bufs = [np.zeros(max(n, 1), np.int32) for _ in range(6)]
+    ptrs = (ctypes.c_void_p * 6)(*[b.ctypes.data for b in bufs])
+    sizes = (ctypes.c_int32 * 6)()
+    lib().orc_wavefront_enqueue_closest(_p(hits), ctypes.c_int(n), _p(hm), _p(pc),
+                                        ctypes.c_int64(0 if pc is None else len(pc)), ptrs, sizes)
+    return [b[:sizes[k]].copy() for k, b in enumerate(bufs)]
+
+
+def record_shadow(occluded, Ld, r_u, r_l, pixel_index, L):
+    """orc_record_shadow: returns the updated copy of L (float32 [n_pixels, 4])."""
+    occ = np.ascontiguousarray(occluded, np.uint8)
+    Ld, r_u, r_l = (np.ascontiguousarray(a, np.float32) for a in (Ld, r_u, r_l))
+    px = np.ascontiguousarray(pixel_index, np.int32)
+    out = np.array(L, np.float32, copy=True)
+    lib().orc_record_shadow(_p(occ), ctypes.c_int(len(occ)), _p(Ld), _p(r_u), _p(r_l), _p(px), _p(out))
+    return out

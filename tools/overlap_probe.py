@@ -19,8 +19,7 @@ primary = np.concatenate([scene.camera_rays("crown", seed=1, sample=s) for s in 
 hits = agg.Intersect(primary)
 bounce = scene.bounce_rays(primary, hits, verts, tris, seed=2)
 lo, hi = verts.min(0), verts.max(0)
-shadow = scene.shadow_rays(primary, hits, verts, tris, lo + (hi - lo) * [0.3, 0.9, 0.3],
-                           lo + (hi - lo) * [0.7, 1.0, 0.7], seed=3)
+shadow = scene.shadow_rays_to_quads(primary, hits, verts, tris, scene.CROWN_LIGHT_QUADS, seed=3)
 dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
 d = [dev(primary), dev(bounce), dev(shadow)]
 n = [len(primary), len(bounce), len(shadow)]

@@ -39,8 +39,7 @@ def main():
     hits = agg.Intersect(primary)
     bounce = scene.bounce_rays(primary, hits, verts, tris, seed=2)
     lo, hi = verts.min(0), verts.max(0)
-    shadow = scene.shadow_rays(primary, hits, verts, tris, lo + (hi - lo) * [0.3, 0.9, 0.3],
-                               lo + (hi - lo) * [0.7, 1.0, 0.7], seed=3)
+    shadow = scene.shadow_rays_to_quads(primary, hits, verts, tris, scene.CROWN_LIGHT_QUADS, seed=3)
     stream = torch.cuda.current_stream().cuda_stream
 
     def dev(a):
