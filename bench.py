@@ -67,6 +67,8 @@ def main():
                     help="tree builder: pbrt split methods, or nn = greedy-SAH top levels of "
                          "machine_learning/nn_BVH.py finished by SAH and baked (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wavefront", action="store_true",
+                    help="also time the step through the wavefront-queue entry points")
     ap.add_argument("--overlapped", action="store_true",
                     help="also time the step as one nnbvh_trace_batches_device call (concurrent "
                          "launches; off by default so that a rocprofv3 kernel average of this "
@@ -232,6 +234,46 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         overlapped_s = float(t.item())
 
+    # ---- the same step through the wavefront-queue entry points (SOA ray queues with
+    # device-side sizes in, index queues and pixel radiance out): opt-in, reported next to `value`
+    wavefront_s = None
+    if args.wavefront:
+        from nn_bvh_amd.wavefront import RayQueue, WavefrontAggregate, WorkQueue
+        from nn_bvh_amd._lib import CLOSEST_QUEUES
+        cdev = torch.device("cuda", local_rank)
+        wf = WavefrontAggregate(agg, np.zeros(len(tris), np.uint8))
+        q_primary, q_bounce = RayQueue.from_records(primary, cdev), RayQueue.from_records(bounce, cdev)
+        q_shadow = RayQueue.from_records(shadow, cdev, shadow=True)
+        outq = {k: WorkQueue(n_primary, cdev) for k in CLOSEST_QUEUES}
+        rng = np.random.default_rng(11)
+        spec = [torch.from_numpy(rng.random((len(shadow), 4), np.float32) + np.float32(0.5)).to(cdev)
+                for _ in range(3)]
+        pix = torch.arange(len(shadow), dtype=torch.int32, device=cdev)
+        L = torch.zeros((len(shadow), 4), dtype=torch.float32, device=cdev)
+        d_hits2 = d_hits.view(-1, 32)
+        d_bhits2 = d_bhits.view(-1, 32)
+
+        def step_wavefront():
+            for q in outq.values():
+                q.Reset()
+            wf.IntersectClosest(n_primary, q_primary, hits=d_hits2, **outq)
+            for q in outq.values():
+                q.Reset()
+            wf.IntersectClosest(len(bounce), q_bounce, hits=d_bhits2, **outq)
+            wf.IntersectShadow(len(shadow), q_shadow, spec[0], spec[1], spec[2], pix, L)
+
+        step_wavefront()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_wavefront()
+        barrier()
+        wavefront_s = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([wavefront_s], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wavefront_s = float(t.item())
+
     allgather_ms = None
     if world > 1:
         # film-sample hand-off after the pass: one RCCL all-gather of the per-tile hit records
@@ -310,6 +352,14 @@ def main():
                 "unit": "Mray/s",
                 "ms_per_step": round(overlapped_s / args.steps * 1e3, 4),
                 "how": "same step as one nnbvh_trace_batches_device call (3 batches concurrent)",
+            }
+        if wavefront_s is not None:
+            result["wavefront_queues"] = {
+                "value": round(total_rays_per_step * args.steps / wavefront_s / 1e6, 2),
+                "unit": "Mray/s",
+                "ms_per_step": round(wavefront_s / args.steps * 1e3, 4),
+                "how": "same step through nnbvh_wavefront_intersect_closest/_shadow: SOA queues in, "
+                       "6 index queues + pixel radiance out, queue resets included",
             }
         if allgather_ms is not None:
             result["allgather_ms"] = round(allgather_ms, 3)

@@ -146,6 +146,26 @@ class HipBVHAggregate {
             fatal("IntersectShadowDevice");
     }
 
+    // ---- whole wavefront stages on the device: the SOA queue in, the reference's destination
+    //      queues (as index queues) and pixel radiance out; see include/nnbvh.h --------------
+    // == WavefrontAggregate::IntersectClosest (wavefront/integrator.h:37-43)
+    void IntersectClosestQueues(int maxRays, const nnbvh_ray_soa &rayQueue, const int32_t *dSize,
+                                const uint8_t *dPrimClass, int64_t nPrimClass, void *dHits,
+                                const nnbvh_closest_queues &out, void *stream) const {
+        if (nnbvh_wavefront_intersect_closest(scene_, maxRays, &rayQueue, dSize, dPrimClass,
+                                              nPrimClass, dHits, &out, stream) != NNBVH_OK)
+            fatal("IntersectClosestQueues");
+    }
+    // == WavefrontAggregate::IntersectShadow (wavefront/integrator.h:45-46)
+    void IntersectShadowQueue(int maxRays, const nnbvh_ray_soa &shadowQueue, const int32_t *dSize,
+                              const float *dLd, const float *dRu, const float *dRl,
+                              const int32_t *dPixelIndex, float *dL, int64_t nPixels,
+                              void *stream, uint8_t *dOccluded = nullptr) const {
+        if (nnbvh_wavefront_intersect_shadow(scene_, maxRays, &shadowQueue, dSize, dLd, dRu, dRl,
+                                             dPixelIndex, dL, nPixels, dOccluded, stream) != NNBVH_OK)
+            fatal("IntersectShadowQueue");
+    }
+
     nnbvh_scene *handle() const { return scene_; }
 
   private:
