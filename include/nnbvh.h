@@ -123,6 +123,18 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
                                             const float *verts, int n_verts,
                                             const float *prim_bounds, int max_prims_in_node,
                                             int split_method);
+/* HLBVH construction on the GPU (`device`): Morton codes, radix sort, the treelets' radix trees,
+ * bounds and the DFS layout are computed on the device, only buildUpperSAH over the <= 4096
+ * treelet roots (aggregates.cpp:626-723) runs on the host.  The result is byte-identical to
+ * nnbvh_build_create_with_bounds(..., NNBVH_SPLIT_HLBVH) — the reference's buildHLBVH
+ * (aggregates.cpp:389-503) with treelets emitted in Morton order.  NULL + nnbvh_last_error() on
+ * failure (no device, allocation, malformed input). */
+nnbvh_build *nnbvh_build_create_gpu(const nnbvh_prim *prims, int n_prims, const float *verts,
+                                    int n_verts, const float *prim_bounds, int max_prims_in_node,
+                                    int device);
+/* milliseconds of the last GPU build's phases: upload, device sort + tree, host upper SAH, device
+ * emit, download (all zero for host builds) */
+int nnbvh_build_gpu_timing(const nnbvh_build *b, double out_ms[5]);
 const nnbvh_linear_node *nnbvh_build_nodes(const nnbvh_build *b, int *n_nodes);
 const nnbvh_prim *nnbvh_build_ordered_prims(const nnbvh_build *b, int *n_prims);
 int nnbvh_build_depth(const nnbvh_build *b); /* edges root -> deepest leaf */

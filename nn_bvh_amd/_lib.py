@@ -39,7 +39,7 @@ EXPORTS = [
     "nnbvh_intersect_any_device", "nnbvh_scene_set_option", "nnbvh_scene_sched_stats",
     "nnbvh_trace_batches_device", "nnbvh_scene_create_instanced", "nnbvh_transform_bounds",
     "nnbvh_build_create_with_bounds", "nnbvh_wavefront_intersect_closest",
-    "nnbvh_wavefront_intersect_shadow",
+    "nnbvh_wavefront_intersect_shadow", "nnbvh_build_create_gpu", "nnbvh_build_gpu_timing",
 ]
 
 _lib = None
@@ -98,6 +98,10 @@ def lib():
     L.nnbvh_build_create_with_bounds.argtypes = [vp, i32, vp, i32, vp, i32, i32]
     L.nnbvh_trace_batches_device.restype = i32
     L.nnbvh_trace_batches_device.argtypes = [vp, vp, i32, vp]
+    L.nnbvh_build_create_gpu.restype = vp
+    L.nnbvh_build_create_gpu.argtypes = [vp, i32, vp, i32, vp, i32, i32]
+    L.nnbvh_build_gpu_timing.restype = i32
+    L.nnbvh_build_gpu_timing.argtypes = [vp, vp]
     L.nnbvh_wavefront_intersect_closest.restype = i32
     L.nnbvh_wavefront_intersect_closest.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp]
     L.nnbvh_wavefront_intersect_shadow.restype = i32

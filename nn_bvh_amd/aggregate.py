@@ -50,6 +50,27 @@ class BuiltTree:
         self.depth = depth
 
 
+def _take_build(L, h, what):
+    if not h:
+        raise NNBVHError(what + ": " + _lib.last_error())
+    try:
+        n = ctypes.c_int(0)
+        pn = L.nnbvh_build_nodes(h, ctypes.byref(n))
+        nodes = np.frombuffer((ctypes.c_char * (n.value * 32)).from_address(pn),
+                              NODE_DTYPE).copy()
+        pp = L.nnbvh_build_ordered_prims(h, ctypes.byref(n))
+        ordered = np.frombuffer((ctypes.c_char * (n.value * 24)).from_address(pp),
+                                PRIM_DTYPE).copy()
+        tree = BuiltTree(nodes, ordered, L.nnbvh_build_depth(h))
+        ms = np.zeros(5, np.float64)
+        L.nnbvh_build_gpu_timing(h, ptr(ms))
+        tree.gpu_ms = dict(zip(("upload", "device_tree", "host_upper_sah", "device_emit", "download"),
+                               (float(x) for x in ms)))
+    finally:
+        L.nnbvh_build_destroy(h)
+    return tree
+
+
 def build_tree(prims, verts, max_prims_in_node=4, split_method="sah", prim_bounds=None):
     """SAH / HLBVH / middle / equal-counts build on the host (no GPU needed).  prim_bounds
     ([n, 6] float32) is required when the list contains instance primitives (kind 2)."""
@@ -67,20 +88,21 @@ def build_tree(prims, verts, max_prims_in_node=4, split_method="sah", prim_bound
     else:
         h = L.nnbvh_build_create(ptr(prims), len(prims), ptr(verts), len(verts),
                                  int(max_prims_in_node), SPLIT_METHODS[split_method])
-    if not h:
-        raise NNBVHError("nnbvh_build_create: " + _lib.last_error())
-    try:
-        n = ctypes.c_int(0)
-        pn = L.nnbvh_build_nodes(h, ctypes.byref(n))
-        nodes = np.frombuffer((ctypes.c_char * (n.value * 32)).from_address(pn),
-                              NODE_DTYPE).copy()
-        pp = L.nnbvh_build_ordered_prims(h, ctypes.byref(n))
-        ordered = np.frombuffer((ctypes.c_char * (n.value * 24)).from_address(pp),
-                                PRIM_DTYPE).copy()
-        depth = L.nnbvh_build_depth(h)
-    finally:
-        L.nnbvh_build_destroy(h)
-    return BuiltTree(nodes, ordered, depth)
+    return _take_build(L, h, "nnbvh_build_create")
+
+
+def build_tree_gpu(prims, verts, max_prims_in_node=4, prim_bounds=None, device=0):
+    """HLBVH built on the GPU: byte-identical to build_tree(..., split_method="hlbvh")."""
+    L = _lib.lib()
+    prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+    verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+    pb = None
+    if prim_bounds is not None:
+        pb = np.ascontiguousarray(prim_bounds, np.float32).reshape(len(prims), 6)
+    h = L.nnbvh_build_create_gpu(ptr(prims), len(prims), ptr(verts), len(verts),
+                                 ptr(pb) if pb is not None else None, int(max_prims_in_node),
+                                 int(device))
+    return _take_build(L, h, "nnbvh_build_create_gpu")
 
 
 class BVHAggregate:

@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "../../include/nnbvh.h"
+#include "bvh_build_gpu.h"
 #include "nnbvh_internal.h"
 
 namespace {
@@ -448,12 +449,73 @@ int flatten(const BuildNode *node, nnbvh_linear_node *out, int *offset, int dept
     return my;
 }
 
+// flattenBVH over the upper tree only: a treelet root takes `size` consecutive slots
+struct UpperFlatten {
+    const int *sizes;
+    nnbvh::UpperLayout *out;
+    int offset = 0;
+    int run(const BuildNode *node, int depth) {
+        const int my = offset;
+        if (node->n < 0) {  // a treelet root, marked by hlbvh_upper_layout
+            const int t = -node->n - 1;
+            out->base[(size_t)t] = my;
+            out->depth[(size_t)t] = depth;
+            offset += sizes[t];
+            return my;
+        }
+        ++offset;
+        nnbvh_linear_node ln;
+        std::memcpy(ln.pmin, node->bounds.mn, 12);
+        std::memcpy(ln.pmax, node->bounds.mx, 12);
+        ln.pad = 0;
+        ln.axis = (uint8_t)node->axis;
+        ln.nprims = 0;
+        run(node->child[0], depth + 1);
+        ln.offset = run(node->child[1], depth + 1);
+        out->upper_index.push_back(my);
+        out->upper_nodes.push_back(ln);
+        return my;
+    }
+};
+
 }  // namespace
+
+namespace nnbvh {
+
+bool hlbvh_upper_layout(const float *treelet_bounds, const int *treelet_sizes, int n_treelets,
+                        UpperLayout *out, std::string *error) {
+    std::vector<BuildNode> treelets((size_t)n_treelets);
+    std::vector<BuildNode *> roots((size_t)n_treelets);
+    for (int t = 0; t < n_treelets; ++t) {
+        std::memcpy(treelets[t].bounds.mn, treelet_bounds + 6 * (size_t)t, 12);
+        std::memcpy(treelets[t].bounds.mx, treelet_bounds + 6 * (size_t)t + 3, 12);
+        treelets[t].n = -(t + 1);  // marker read by UpperFlatten (upper() makes nodes with n = 0)
+        roots[t] = &treelets[t];
+    }
+    Builder b;
+    std::vector<BuildPrim> none;
+    HLBuilder hl{b, none, {}};
+    BuildNode *root = hl.upper(roots, 0, n_treelets);
+    if (!root) {
+        *error = "nnbvh_build_create: " + hl.error;
+        return false;
+    }
+    out->base.assign((size_t)n_treelets, 0);
+    out->depth.assign((size_t)n_treelets, 0);
+    UpperFlatten f{treelet_sizes, out};
+    f.run(root, 0);
+    out->total_nodes = f.offset;
+    return true;
+}
+
+}  // namespace nnbvh
 
 struct nnbvh_build {
     std::vector<nnbvh_linear_node> nodes;
     std::vector<nnbvh_prim> ordered;
     int depth = 0;
+    double gpu_ms[5] = {0, 0, 0, 0, 0};
+    int n_treelets = 0, n_unique_codes = 0;
 };
 
 extern "C" {
@@ -540,6 +602,39 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
                      ms(t1, t2), ms(t2, now()));
     }
     return out;
+}
+
+nnbvh_build *nnbvh_build_create_gpu(const nnbvh_prim *prims, int n_prims, const float *verts,
+                                    int n_verts, const float *prim_bounds, int max_prims_in_node,
+                                    int device) {
+    if (!prims || !verts || n_prims <= 0 || n_verts <= 0) {
+        nnbvh::set_error("nnbvh_build_create_gpu: empty primitive or vertex array");
+        return nullptr;
+    }
+    nnbvh::GpuBuildResult r;
+    std::string err;
+    if (!nnbvh::gpu_hlbvh(prims, n_prims, verts, n_verts, prim_bounds, max_prims_in_node, device, &r, &err)) {
+        nnbvh::set_error(err);
+        return nullptr;
+    }
+    auto *out = new nnbvh_build;
+    out->nodes.swap(r.nodes);
+    out->ordered.swap(r.ordered);
+    out->depth = r.depth;
+    std::memcpy(out->gpu_ms, r.ms, sizeof r.ms);
+    out->n_treelets = r.n_treelets;
+    out->n_unique_codes = r.n_unique_codes;
+    if (std::getenv("NNBVH_BUILD_TIMING"))
+        std::fprintf(stderr, "nnbvh_build (gpu hlbvh): upload %.1f ms, device sort+tree %.1f ms, upper SAH (host) "
+                             "%.1f ms, emit %.1f ms, download %.1f ms; %d distinct codes, %d treelets\n",
+                     r.ms[0], r.ms[1], r.ms[2], r.ms[3], r.ms[4], r.n_unique_codes, r.n_treelets);
+    return out;
+}
+
+int nnbvh_build_gpu_timing(const nnbvh_build *b, double out_ms[5]) {
+    if (!b || !out_ms) return NNBVH_ERR_ARG;
+    std::memcpy(out_ms, b->gpu_ms, sizeof b->gpu_ms);
+    return NNBVH_OK;
 }
 
 const nnbvh_linear_node *nnbvh_build_nodes(const nnbvh_build *b, int *n_nodes) {

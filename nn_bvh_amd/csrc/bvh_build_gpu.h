@@ -1,0 +1,41 @@
+// bvh_build_gpu.h — interface between the host builder (bvh_build.cpp) and the device HLBVH
+// pipeline (bvh_build_gpu.hip).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/nnbvh.h"
+
+namespace nnbvh {
+
+// Upper levels of an HLBVH (buildUpperSAH, cpu/aggregates.cpp:626-723) over treelet roots given
+// by bounds (6 floats each) and subtree node counts, laid out in flattenBVH's DFS order
+// (aggregates.cpp:505-522): where every treelet's nodes start, how deep its root sits, and the
+// upper interior nodes themselves.
+struct UpperLayout {
+    std::vector<int> base;    // [nTreelets] flat index of the treelet's root
+    std::vector<int> depth;   // [nTreelets] depth of the treelet's root
+    std::vector<int> upper_index;                 // flat indices of the upper interior nodes
+    std::vector<nnbvh_linear_node> upper_nodes;   // ... and their contents
+    int total_nodes = 0;
+};
+bool hlbvh_upper_layout(const float *treelet_bounds, const int *treelet_sizes, int n_treelets,
+                        UpperLayout *out, std::string *error);
+
+struct GpuBuildResult {
+    std::vector<nnbvh_linear_node> nodes;
+    std::vector<nnbvh_prim> ordered;
+    int depth = 0;
+    // milliseconds: host->device copies, device pipeline up to the treelet table, host upper tree,
+    // device emit, device->host copies
+    double ms[5] = {0, 0, 0, 0, 0};
+    int n_treelets = 0, n_unique_codes = 0;
+};
+// prim_bounds may be NULL when every primitive is a triangle or a bilinear patch.
+bool gpu_hlbvh(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
+               const float *prim_bounds, int max_prims_in_node, int device, GpuBuildResult *out,
+               std::string *error);
+
+}  // namespace nnbvh

@@ -1,0 +1,98 @@
+"""HLBVH construction on the GPU (nnbvh_build_create_gpu) against the host builder's HLBVH, which
+restates the reference's buildHLBVH (cpu/aggregates.cpp:389-503, 626-723) with treelets emitted in
+Morton order: the flattened LinearBVHNode array and the leaf-ordered primitive table must be
+BYTE-IDENTICAL (same Morton codes, same stable sort, same splits, same bounds incl. the sign of
+zeros, same DFS layout)."""
+import os
+
+import numpy as np
+import pytest
+
+import scenes_small as ss
+from nn_bvh_amd import NNBVHError, build_tree, build_tree_gpu, make_prims, scene
+
+pytestmark = pytest.mark.gpu
+
+
+def same_tree(prims, verts, max_prims=4, prim_bounds=None, what=""):
+    host = build_tree(prims, verts, max_prims, "hlbvh", prim_bounds=prim_bounds)
+    dev = build_tree_gpu(prims, verts, max_prims, prim_bounds=prim_bounds)
+    assert len(dev.nodes) == len(host.nodes), f"{what}: {len(dev.nodes)} vs {len(host.nodes)} nodes"
+    assert dev.ordered_prims.tobytes() == host.ordered_prims.tobytes(), f"{what}: ordered prims differ"
+    if dev.nodes.tobytes() != host.nodes.tobytes():
+        a = dev.nodes.view(np.uint8).reshape(-1, 32)
+        b = host.nodes.view(np.uint8).reshape(-1, 32)
+        bad = np.nonzero((a != b).any(1))[0]
+        raise AssertionError(f"{what}: {len(bad)} nodes differ, first {bad[:5]}: "
+                             f"{dev.nodes[bad[:3]]} vs {host.nodes[bad[:3]]}")
+    assert dev.depth == host.depth, f"{what}: depth {dev.depth} vs {host.depth}"
+    return host
+
+
+@pytest.mark.parametrize("max_prims", [1, 2, 4, 16, 255])
+def test_soup_with_patches(max_prims):
+    verts, prims = ss.random_soup(6000, 1500, 3)
+    same_tree(prims, verts, max_prims, what=f"soup maxprims {max_prims}")
+
+
+def test_connected_mesh_and_duplicate_codes():
+    verts, prims = ss.grid_mesh(96, 2)
+    same_tree(prims, verts, what="grid")
+    # many primitives with one centroid -> one Morton code -> one big leaf whatever maxPrims is
+    verts, prims = ss.coincident_centroids(400, 5)
+    host = same_tree(prims, verts, what="coincident")
+    assert host.nodes["nprims"].max() >= 300
+    # clustered: few treelets, long runs of equal codes next to distinct ones
+    rng = np.random.default_rng(9)
+    v1, p1 = ss.random_soup(3000, 0, 6, extent=0.001, size=0.0004)
+    v2, p2 = ss.random_soup(2000, 0, 7, extent=50.0)
+    p2 = p2.copy()
+    p2["v"][:, :3] += len(v1)
+    p2["id"] += len(p1)
+    same_tree(np.concatenate([p1, p2]), np.concatenate([v1, v2]), what="clustered")
+    del rng
+
+
+def test_tiny_inputs():
+    for n in (1, 2, 3, 5):
+        verts, prims = ss.random_soup(n, 0, 20 + n)
+        same_tree(prims, verts, what=f"{n} prims")
+    # two primitives in the same place: a single distinct code
+    verts, prims = ss.random_soup(1, 0, 30)
+    verts2 = np.concatenate([verts, verts])
+    prims2 = np.concatenate([prims, prims])
+    prims2["v"][1, :3] += len(verts)
+    prims2["id"][1] = 1
+    same_tree(prims2, verts2, what="two coincident prims")
+
+
+def test_caller_supplied_bounds_for_instance_and_host_primitives():
+    verts, prims = ss.random_soup(3000, 200, 8)
+    rng = np.random.default_rng(4)
+    extra = np.zeros(40, prims.dtype)
+    extra["kind"] = np.where(np.arange(40) % 2 == 0, 2, 3)
+    extra["id"] = len(prims) + np.arange(40)
+    extra["v"][:, 0] = np.arange(40)
+    allp = np.concatenate([prims, extra])
+    lo = rng.uniform(-8, 8, (len(allp), 3)).astype(np.float32)
+    pb = np.concatenate([lo, lo + rng.uniform(0.1, 2, (len(allp), 3)).astype(np.float32)], 1)
+    same_tree(allp, verts, prim_bounds=pb, what="with instance/host prims")
+    with pytest.raises(NNBVHError, match="need prim_bounds"):
+        build_tree_gpu(allp, verts)
+
+
+def test_bad_vertex_index_is_an_error_not_a_fault():
+    verts, prims = ss.random_soup(500, 0, 9)
+    prims = prims.copy()
+    prims["v"][123, 1] = len(verts) + 7
+    with pytest.raises(NNBVHError, match="vertex index out of range"):
+        build_tree_gpu(prims, verts)
+
+
+@pytest.mark.parametrize("name", ["killeroos", "bathroom", "crown"])
+def test_scene_blobs(name):
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "..", "data", name + ".npz")):
+        pytest.skip(f"data/{name}.npz not present")
+    verts, tris = scene.load_blob(name)
+    host = same_tree(make_prims(tris), verts, what=name)
+    assert len(host.nodes) > 1000 and host.nodes["nprims"].sum() == len(tris)
