@@ -15,7 +15,11 @@ DRIVER = textwrap.dedent(r'''
     #include <string>
     #include <vector>
     #include "nnbvh.h"
-    namespace nnbvh { void set_error(const std::string &m) { std::fprintf(stderr, "err: %s\n", m.c_str()); } }
+    #include "bvh_build_gpu.h"
+    namespace nnbvh { void set_error(const std::string &m) { std::fprintf(stderr, "err: %s\n", m.c_str()); }
+    // the device pipeline lives in bvh_build_gpu.hip, which a CPU-only sanitizer build cannot link
+    bool gpu_hlbvh(const nnbvh_prim *, int, const float *, int, const float *, int, int, GpuBuildResult *,
+                   std::string *e) { *e = "no device code in this build"; return false; } }
     int main() {
         std::mt19937 rng(3);
         std::uniform_real_distribution<float> U(-1.f, 1.f);
@@ -45,6 +49,34 @@ DRIVER = textwrap.dedent(r'''
                     nnbvh_build_destroy(b);
                 }
         }
+        // the host half of the GPU HLBVH build: upper SAH tree + DFS layout over treelet roots
+        for (int nt : {1, 2, 37, 4096}) {
+            std::vector<float> tb(6 * (size_t)nt);
+            std::vector<int> ts(nt);
+            for (int t = 0; t < nt; ++t) {
+                for (int a = 0; a < 3; ++a) {
+                    tb[6 * t + a] = 50 * U(rng);
+                    tb[6 * t + 3 + a] = tb[6 * t + a] + 1 + U(rng) * 0.5f;
+                }
+                ts[t] = 1 + 2 * (int)(rng() % 9);
+            }
+            nnbvh::UpperLayout up;
+            std::string err;
+            if (!nnbvh::hlbvh_upper_layout(tb.data(), ts.data(), nt, &up, &err)) return 2;
+            long want = nt - 1;
+            for (int t = 0; t < nt; ++t) want += ts[t];
+            if (up.total_nodes != want || (int)up.upper_index.size() != nt - 1) return 3;
+            std::vector<char> used((size_t)up.total_nodes, 0);
+            for (int t = 0; t < nt; ++t)
+                for (int k = 0; k < ts[t]; ++k) {
+                    if (used[(size_t)up.base[t] + k]) return 4;  // treelet regions must not overlap
+                    used[(size_t)up.base[t] + k] = 1;
+                }
+            for (int i : up.upper_index) {
+                if (used[(size_t)i]) return 5;
+                used[(size_t)i] = 1;
+            }
+        }
         std::puts("sanitized builder ok");
         return 0;
     }
@@ -57,6 +89,7 @@ def test_builder_under_asan_ubsan(tmp_path):
     exe = tmp_path / "driver"
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
                     "-fno-sanitize-recover=all", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.join(ROOT, "nn_bvh_amd", "csrc"),
                     str(src), os.path.join(ROOT, "nn_bvh_amd", "csrc", "bvh_build.cpp"), "-o", str(exe)],
                    check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True,
@@ -72,7 +105,11 @@ TSAN_DRIVER = textwrap.dedent(r'''
     #include <string>
     #include <vector>
     #include "nnbvh.h"
-    namespace nnbvh { void set_error(const std::string &m) { std::fprintf(stderr, "err: %s\n", m.c_str()); } }
+    #include "bvh_build_gpu.h"
+    namespace nnbvh { void set_error(const std::string &m) { std::fprintf(stderr, "err: %s\n", m.c_str()); }
+    // the device pipeline lives in bvh_build_gpu.hip, which a CPU-only sanitizer build cannot link
+    bool gpu_hlbvh(const nnbvh_prim *, int, const float *, int, const float *, int, int, GpuBuildResult *,
+                   std::string *e) { *e = "no device code in this build"; return false; } }
     int main() {
         // 300 000 primitives: above the 128 K threshold, so sub-trees are built by separate threads
         const int n = 300000;
@@ -104,7 +141,8 @@ def test_threaded_builder_under_tsan(tmp_path):
     src.write_text(TSAN_DRIVER)
     exe = tmp_path / "driver"
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-ffp-contract=off",
-                    "-I", os.path.join(ROOT, "include"), str(src),
+                    "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.join(ROOT, "nn_bvh_amd", "csrc"), str(src),
                     os.path.join(ROOT, "nn_bvh_amd", "csrc", "bvh_build.cpp"), "-o", str(exe), "-lpthread"],
                    check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
