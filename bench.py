@@ -269,6 +269,26 @@ def main():
             step_wavefront()
         barrier()
         wavefront_s = time.perf_counter() - t1
+        # ... and with the hit -> SurfaceInteraction post-pass of both closest-hit stages
+        # (Triangle::InteractionFromIntersection, which the reference's Intersect runs per hit)
+        from nn_bvh_amd.interaction import ShadingMesh
+        smesh = ShadingMesh(verts, tris, device=local_rank)
+        d_intr = torch.empty(n_primary * 160, dtype=torch.uint8, device=cdev)
+
+        def step_wavefront_intr():
+            step_wavefront()
+            smesh.interactions_device(d_hits2.data_ptr(), n_primary, d_intr.data_ptr(), ray_queue=q_primary,
+                                      stream=stream)
+            smesh.interactions_device(d_bhits2.data_ptr(), len(bounce), d_intr.data_ptr(), ray_queue=q_bounce,
+                                      stream=stream)
+
+        step_wavefront_intr()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_wavefront_intr()
+        barrier()
+        wavefront_intr_s = time.perf_counter() - t1
         if world > 1:
             t = torch.tensor([wavefront_s], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -360,6 +380,7 @@ def main():
                 "ms_per_step": round(wavefront_s / args.steps * 1e3, 4),
                 "how": "same step through nnbvh_wavefront_intersect_closest/_shadow: SOA queues in, "
                        "6 index queues + pixel radiance out, queue resets included",
+                "with_surface_interactions_ms_per_step": round(wavefront_intr_s / args.steps * 1e3, 4),
             }
         if allgather_ms is not None:
             result["allgather_ms"] = round(allgather_ms, 3)

@@ -16,6 +16,7 @@
  *                              like CPUAggregate::IntersectShadow  (wavefront/aggregate.cpp:60-68)
  *   nnbvh_wavefront_*       <- WavefrontAggregate::IntersectClosest / IntersectShadow incl. the
  *                              queue push rules (wavefront/integrator.h:32-54, intersect.h:16-156)
+ *   nnbvh_triangle_interactions_device <- Triangle::InteractionFromIntersection (shapes.h:884-1010)
  *   nnbvh_build_*           <- BVHAggregate ctor + buildRecursive + flattenBVH
  *                              (cpu/aggregates.cpp:140-387, 505-522); host-side, no GPU needed
  *
@@ -252,6 +253,54 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
                                      const int32_t *d_size, const float *d_Ld, const float *d_r_u,
                                      const float *d_r_l, const int32_t *d_pixel_index, float *d_L,
                                      int64_t n_pixels, uint8_t *d_occluded, void *stream);
+
+/* ---- hit record -> SurfaceInteraction: Triangle::InteractionFromIntersection -----------------
+ * (shapes.h:884-1010, run by Triangle::Intersect, shapes.cpp:302-334, on every reported hit; with
+ * the SurfaceInteraction constructor and SetShadingGeometry, interaction.h:32-33, 164-214).  A
+ * device post-pass over a batch of hit records; bit-identical to the reference function.
+ * The mesh data are TriangleMesh's (util/mesh.h:24-72) flattened over all meshes of the scene, in
+ * render space and as the TriangleMesh constructor stores them (util/mesh.cpp:36-64: normals
+ * negated under reverseOrientation). */
+#define NNBVH_TRI_FLIP_NORMAL 1 /* mesh->reverseOrientation ^ mesh->transformSwapsHandedness */
+#define NNBVH_TRI_HAS_UV 2      /* the triangle's mesh has uv / n / s (meshes of one scene differ) */
+#define NNBVH_TRI_HAS_N 4
+#define NNBVH_TRI_HAS_S 8
+typedef struct nnbvh_shading_mesh nnbvh_shading_mesh;
+/* tri_vertices: 3 vertex indices per triangle, triangle k being the primitive whose nnbvh_prim.id
+ * is k (v[0] < 0: not a triangle).  normals / tangents: 3 floats per vertex, uvs: 2, face_indices:
+ * 1 int per triangle; each nullable.  tri_flags: NNBVH_TRI_* per triangle; NULL = no flip and the
+ * HAS_* bits follow from which arrays were given. */
+nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
+                                              const int32_t *tri_vertices, int n_tris,
+                                              const float *normals, const float *uvs,
+                                              const float *tangents, const int32_t *face_indices,
+                                              const uint8_t *tri_flags, int device);
+void nnbvh_shading_mesh_destroy(nnbvh_shading_mesh *m);
+
+#define NNBVH_INTERACTION_MISS 0
+#define NNBVH_INTERACTION_TRIANGLE 1 /* fields below are valid */
+#define NNBVH_INTERACTION_HOST 2     /* hit on a bilinear patch, inside an instance or on a host
+                                        primitive: the caller finishes it on the host */
+typedef struct nnbvh_interaction {   /* 160 B */
+    float pi_lo[3], pi_hi[3]; /* Point3fi pi = pHit +- gamma(7) sum|b_i p_i| (shapes.h:926-930) */
+    float uv[2];
+    float wo[3];              /* Normalize(-ray.d) */
+    float time;
+    float n[3];               /* geometric normal after FaceForward to the shading normal */
+    int32_t face_index;
+    float dpdu[3], dpdv[3];
+    float ns[3], dpdus[3], dpdvs[3], dndus[3], dndvs[3]; /* SurfaceInteraction::shading */
+    int32_t prim;             /* the hit record's primitive id, -1 = miss */
+    int32_t status;           /* NNBVH_INTERACTION_* */
+    int32_t pad;
+} nnbvh_interaction;
+/* One of d_rays (nnbvh_ray[max_items]) / ray_soa gives the rays the hits belong to (direction and
+ * time are read).  n = min(max_items, *d_size) when d_size != NULL.  d_out: nnbvh_interaction
+ * [max_items], record i for hit i. */
+int nnbvh_triangle_interactions_device(const nnbvh_shading_mesh *m, const void *d_rays,
+                                       const nnbvh_ray_soa *ray_soa, const void *d_hits,
+                                       int32_t max_items, const int32_t *d_size, void *d_out,
+                                       void *stream);
 
 /* tuning knobs (speed only, never results): "stack_window" (LDS entries per lane: 4, 8, 16),
  * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "prim_weight" / "refill_weight" (1..64:

@@ -27,6 +27,13 @@ CLOSEST_QUEUES = ("escaped", "hit_area_light", "basic_eval_material", "universal
                   "medium_sample", "next_ray")
 CLOSEST_QUEUES_DTYPE = np.dtype([(k, WORK_QUEUE_DTYPE) for k in CLOSEST_QUEUES])
 CLASS_BASIC, CLASS_UNIVERSAL, CLASS_INTERFACE, CLASS_AREA_LIGHT = 0, 1, 2, 4
+INTERACTION_DTYPE = np.dtype([("pi_lo", "<f4", 3), ("pi_hi", "<f4", 3), ("uv", "<f4", 2), ("wo", "<f4", 3),
+                              ("time", "<f4"), ("n", "<f4", 3), ("face_index", "<i4"), ("dpdu", "<f4", 3),
+                              ("dpdv", "<f4", 3), ("ns", "<f4", 3), ("dpdus", "<f4", 3), ("dpdvs", "<f4", 3),
+                              ("dndus", "<f4", 3), ("dndvs", "<f4", 3), ("prim", "<i4"), ("status", "<i4"),
+                              ("pad", "<i4")])
+TRI_FLIP_NORMAL, TRI_HAS_UV, TRI_HAS_N, TRI_HAS_S = 1, 2, 4, 8
+assert INTERACTION_DTYPE.itemsize == 160
 assert NODE_DTYPE.itemsize == 32 and PRIM_DTYPE.itemsize == 24
 assert RAY_SOA_DTYPE.itemsize == 72 and CLOSEST_QUEUES_DTYPE.itemsize == 6 * 24
 assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 32
@@ -40,6 +47,7 @@ EXPORTS = [
     "nnbvh_trace_batches_device", "nnbvh_scene_create_instanced", "nnbvh_transform_bounds",
     "nnbvh_build_create_with_bounds", "nnbvh_wavefront_intersect_closest",
     "nnbvh_wavefront_intersect_shadow", "nnbvh_build_create_gpu", "nnbvh_build_gpu_timing",
+    "nnbvh_shading_mesh_create", "nnbvh_shading_mesh_destroy", "nnbvh_triangle_interactions_device",
 ]
 
 _lib = None
@@ -102,6 +110,12 @@ def lib():
     L.nnbvh_build_create_gpu.argtypes = [vp, i32, vp, i32, vp, i32, i32]
     L.nnbvh_build_gpu_timing.restype = i32
     L.nnbvh_build_gpu_timing.argtypes = [vp, vp]
+    L.nnbvh_shading_mesh_create.restype = vp
+    L.nnbvh_shading_mesh_create.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32]
+    L.nnbvh_shading_mesh_destroy.restype = None
+    L.nnbvh_shading_mesh_destroy.argtypes = [vp]
+    L.nnbvh_triangle_interactions_device.restype = i32
+    L.nnbvh_triangle_interactions_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     L.nnbvh_wavefront_intersect_closest.restype = i32
     L.nnbvh_wavefront_intersect_closest.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp]
     L.nnbvh_wavefront_intersect_shadow.restype = i32

@@ -44,8 +44,7 @@ namespace nnbvh {
 namespace {
 
 constexpr int kB = 256;
-constexpr unsigned kTreeletMask = 0x3ffc0000u;  // aggregates.cpp:423
-constexpr int kTreeletBit = 18;                 // bits >= 18 separate treelets
+constexpr int kTreeletBit = 18;  // bits >= 18 separate treelets (mask 0x3ffc0000, aggregates.cpp:423)
 
 enum : int { kErrVertex = 1, kErrNeedBounds = 2, kErrKind = 3, kErrLeafSize = 4 };
 enum : unsigned char { kRealInterior = 1, kRealLeaf = 2, kTreeletRoot = 4 };

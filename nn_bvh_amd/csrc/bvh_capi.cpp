@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "bvh_trace.h"
+#include "interaction.h"
 #include "wavefront.h"
 
 namespace nnbvh {
@@ -773,6 +774,100 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
     if (!hip_ok(launch_wf_record_shadow(occ, cnt, d_Ld, d_r_u, d_r_l, d_pixel_index, d_L, (long)n_pixels,
                                         max_blocks, stream),
                 "shadow record kernel launch"))
+        return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
+}
+
+// ---- Triangle::InteractionFromIntersection post-pass (shapes.h:884-1010) --------------------------
+static_assert(sizeof(nnbvh_interaction) == 160, "nnbvh_interaction must be 160 bytes");
+
+}  // extern "C"
+
+struct nnbvh_shading_mesh {
+    int device = 0;
+    int n_cus = 0;
+    ShadingMeshDevice d;
+};
+
+template <typename T>
+static bool upload(T **dst, const T *src, size_t count, const char *what) {
+    *dst = nullptr;
+    if (!src || count == 0) return true;
+    return hip_ok(hipMalloc((void **)dst, count * sizeof(T)), what) &&
+           hip_ok(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice), what);
+}
+
+extern "C" {
+
+nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
+                                              const int32_t *tri_vertices, int n_tris,
+                                              const float *normals, const float *uvs,
+                                              const float *tangents, const int32_t *face_indices,
+                                              const uint8_t *tri_flags, int device) {
+    if (!verts || !tri_vertices || n_verts <= 0 || n_tris <= 0) {
+        set_error("shading_mesh_create: empty vertex or triangle array");
+        return nullptr;
+    }
+    for (long i = 0; i < 3L * n_tris; ++i) {
+        const int v = tri_vertices[i];
+        const bool not_a_triangle = tri_vertices[i - i % 3] < 0;
+        if (!not_a_triangle && (v < 0 || v >= n_verts)) {
+            set_error("shading_mesh_create: vertex index out of range");
+            return nullptr;
+        }
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return nullptr;
+    auto *m = new nnbvh_shading_mesh;
+    m->device = device;
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) {
+        delete m;
+        return nullptr;
+    }
+    m->n_cus = prop.multiProcessorCount;
+    m->d.nTris = n_tris;
+    m->d.nVerts = n_verts;
+    m->d.defaultFlags = (uvs ? NNBVH_TRI_HAS_UV : 0) | (normals ? NNBVH_TRI_HAS_N : 0) |
+                        (tangents ? NNBVH_TRI_HAS_S : 0);
+    const bool ok = upload(&m->d.verts, verts, 3 * (size_t)n_verts, "shading mesh: vertices") &&
+                    upload(&m->d.triVerts, tri_vertices, 3 * (size_t)n_tris, "shading mesh: indices") &&
+                    upload(&m->d.normals, normals, 3 * (size_t)n_verts, "shading mesh: normals") &&
+                    upload(&m->d.uvs, uvs, 2 * (size_t)n_verts, "shading mesh: uvs") &&
+                    upload(&m->d.tangents, tangents, 3 * (size_t)n_verts, "shading mesh: tangents") &&
+                    upload(&m->d.faceIndices, face_indices, (size_t)n_tris, "shading mesh: face indices") &&
+                    upload(&m->d.triFlags, tri_flags, (size_t)n_tris, "shading mesh: flags");
+    if (!ok) {
+        nnbvh_shading_mesh_destroy(m);
+        return nullptr;
+    }
+    return m;
+}
+
+void nnbvh_shading_mesh_destroy(nnbvh_shading_mesh *m) {
+    if (!m) return;
+    DeviceGuard guard(m->device);
+    void *ptrs[] = {m->d.verts, m->d.triVerts, m->d.normals, m->d.uvs, m->d.tangents, m->d.faceIndices, m->d.triFlags};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+int nnbvh_triangle_interactions_device(const nnbvh_shading_mesh *m, const void *d_rays,
+                                       const nnbvh_ray_soa *ray_soa, const void *d_hits,
+                                       int32_t max_items, const int32_t *d_size, void *d_out,
+                                       void *stream) {
+    const bool soa_given = ray_soa && ray_soa->dx && ray_soa->dy && ray_soa->dz;
+    if (!m || max_items < 0 || (max_items > 0 && (!d_hits || !d_out || (!d_rays && !soa_given)))) {
+        set_error("triangle_interactions_device: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    if (max_items == 0) return NNBVH_OK;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    if (!hip_ok(launch_triangle_interactions(m->d, d_rays, d_rays ? nullptr : ray_soa, d_hits, max_items, d_size,
+                                             d_out, m->n_cus * 8, (hipStream_t)stream),
+                "interaction kernel launch"))
         return NNBVH_ERR_DEVICE;
     return NNBVH_OK;
 }

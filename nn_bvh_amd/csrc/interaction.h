@@ -1,0 +1,24 @@
+// interaction.h — launch interface of the hit -> SurfaceInteraction post-pass (interaction.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nnbvh.h"
+
+namespace nnbvh {
+
+struct ShadingMeshDevice {  // device pointers of a nnbvh_shading_mesh
+    float *verts = nullptr;
+    int32_t *triVerts = nullptr;
+    float *normals = nullptr, *uvs = nullptr, *tangents = nullptr;
+    int32_t *faceIndices = nullptr;
+    uint8_t *triFlags = nullptr;
+    int nTris = 0, nVerts = 0;
+    unsigned defaultFlags = 0;
+};
+
+hipError_t launch_triangle_interactions(const ShadingMeshDevice &m, const void *rays, const nnbvh_ray_soa *soa,
+                                        const void *hits, int n, const int32_t *nDev, void *out, int maxBlocks,
+                                        hipStream_t stream);
+
+}  // namespace nnbvh

@@ -1,0 +1,267 @@
+// interaction.hip — Triangle::InteractionFromIntersection on the device
+// (/root/reference/src/pbrt/shapes.h:884-1010, with the SurfaceInteraction constructor and
+// SetShadingGeometry it runs: interaction.h:32-33, 164-214).
+//
+// The traversal kernels return what TriangleIntersection carries (primitive, b0 b1 b2, t);
+// Triangle::Intersect (shapes.cpp:302-334) then builds the SurfaceInteraction every later stage of
+// the reference reads (wavefront/intersect.h:49-156 copies pi, n, dpdu, dpdv, uv, shading.* and
+// faceIndex into its work items).  This is that post-pass for a whole batch of hit records: one
+// thread per item, ~250 flops, 80-190 B gathered (hit, ray direction + time, 3 vertex indices,
+// 3 positions, optional uv / normal / tangent triples) and 160 B written — a streaming, HBM-bound
+// pass a few percent of the trace it follows.
+//
+// Arithmetic is the reference's, operation for operation (FMA exactly where DifferenceOfProducts /
+// SumOfProducts / the Normal3 Dot use it, IEEE division and square root, the float vs double
+// literal of the two degenerate-uv tests); tests/test_interaction.py checks the kernel bit for
+// bit against vectors produced by the compiled reference function.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "interaction.h"
+
+namespace nnbvh {
+
+#define IDEV static __device__ __forceinline__
+
+struct F3 {
+    float x, y, z;
+};
+IDEV F3 f3(const float *p) { return {p[0], p[1], p[2]}; }
+IDEV F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+IDEV F3 neg(F3 a) { return {-a.x, -a.y, -a.z}; }
+IDEV F3 scale(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }  // Tuple3::operator*(U): vecmath.h:350-353
+IDEV float len2(F3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }   // vecmath.h:948-950
+IDEV float gamma7() { return (7.0f * 0x1p-24f) / (1.0f - 7.0f * 0x1p-24f); }  // float.h:195-197
+
+IDEV float dop(float a, float b, float c, float d) {  // math.h:569-575
+    const float cd = c * d;
+    const float diff = __builtin_fmaf(a, b, -cd);
+    const float err = __builtin_fmaf(-c, d, cd);
+    return diff + err;
+}
+IDEV float sop(float a, float b, float c, float d) {  // math.h:577-583
+    const float cd = c * d;
+    const float s = __builtin_fmaf(a, b, cd);
+    const float err = __builtin_fmaf(c, d, -cd);
+    return s + err;
+}
+IDEV F3 dop_v(float a, F3 b, float c, F3 d) {  // the same with the vector FMA of vecmath.h:415-417
+    return {dop(a, b.x, c, d.x), dop(a, b.y, c, d.y), dop(a, b.z, c, d.z)};
+}
+IDEV F3 cross(F3 v, F3 w) {  // vecmath.h:932-945, 999-1004
+    return {dop(v.y, w.z, v.z, w.y), dop(v.z, w.x, v.x, w.z), dop(v.x, w.y, v.y, w.x)};
+}
+IDEV float dot_n(F3 n, F3 v) {  // Dot(Normal3, .): vecmath.h:1056-1075
+    return __builtin_fmaf(n.x, v.x, sop(n.y, v.y, n.z, v.z));
+}
+IDEV F3 normalize(F3 v) {  // v / Length(v): vecmath.h:953-961, 362-365
+    const float len = __builtin_sqrtf(len2(v));
+    return {v.x / len, v.y / len, v.z / len};
+}
+IDEV void coordinate_system(F3 v1, F3 &v2, F3 &v3) {  // vecmath.h:1007-1013
+    const float sign = __builtin_copysignf(1.0f, v1.z);
+    const float a = -1 / (sign + v1.z);
+    const float b = v1.x * v1.y * a;
+    v2 = {1 + sign * (v1.x * v1.x) * a, sign * b, -sign * v1.x};
+    v3 = {b, sign + (v1.y * v1.y) * a, -v1.y};
+}
+IDEV F3 bary(float b0, float b1, float b2, F3 a0, F3 a1, F3 a2) {  // b0 * a0 + b1 * a1 + b2 * a2
+    return {(b0 * a0.x + b1 * a1.x) + b2 * a2.x, (b0 * a0.y + b1 * a1.y) + b2 * a2.y,
+            (b0 * a0.z + b1 * a1.z) + b2 * a2.z};
+}
+// NextFloatUp / NextFloatDown (float.h:163-193) and Interval::FromValueAndError (math.h:829-838)
+IDEV float next_up(float v) {
+    if (__builtin_isinf(v) && v > 0.f) return v;
+    if (v == -0.f) v = 0.f;
+    unsigned ui = __float_as_uint(v);
+    if (v >= 0) ++ui;
+    else --ui;
+    return __uint_as_float(ui);
+}
+IDEV float next_down(float v) {
+    if (__builtin_isinf(v) && v < 0.f) return v;
+    if (v == 0.f) v = -0.f;
+    unsigned ui = __float_as_uint(v);
+    if (v > 0) --ui;
+    else ++ui;
+    return __uint_as_float(ui);
+}
+
+struct MeshView {
+    const float *verts;
+    const int32_t *triVerts;
+    const float *normals, *uvs, *tangents;
+    const int32_t *faceIndices;
+    const uint8_t *triFlags;
+    int nTris;
+    unsigned defaultFlags;
+};
+
+__global__ __launch_bounds__(256) void k_triangle_interactions(
+    MeshView m, const float4 *__restrict__ rays, nnbvh_ray_soa soa, const float4 *__restrict__ hits, int n,
+    const int32_t *nDev, nnbvh_interaction *__restrict__ out) {
+    if (nDev) {
+        const int nd = *nDev;
+        n = nd < 0 ? 0 : (nd < n ? nd : n);
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 h0 = hits[2 * (long)i], h1 = hits[2 * (long)i + 1];
+        const int prim = __float_as_int(h0.x);
+        nnbvh_interaction r;
+        __builtin_memset(&r, 0, sizeof r);
+        r.prim = prim;
+        r.status = NNBVH_INTERACTION_MISS;
+        if (prim >= 0) {
+            const bool hostCase = __float_as_int(h1.w) != 0 || prim >= m.nTris || m.triVerts[3 * (long)prim] < 0;
+            r.status = hostCase ? NNBVH_INTERACTION_HOST : NNBVH_INTERACTION_TRIANGLE;
+        }
+        if (r.status != NNBVH_INTERACTION_TRIANGLE) {
+            out[i] = r;
+            continue;
+        }
+        F3 wo;
+        float time;
+        if (rays) {
+            const float4 r1 = rays[2 * (long)i + 1];
+            wo = {-r1.x, -r1.y, -r1.z};  // Triangle::Intersect passes -ray.d (shapes.cpp:331)
+            time = r1.w;
+        } else {
+            wo = {-soa.dx[i], -soa.dy[i], -soa.dz[i]};
+            time = soa.time ? soa.time[i] : 0.0f;
+        }
+        const float b0 = h0.z, b1 = h0.w, b2 = h1.x;
+        const int v0 = m.triVerts[3 * (long)prim], v1 = m.triVerts[3 * (long)prim + 1],
+                  v2 = m.triVerts[3 * (long)prim + 2];
+        const unsigned flags = m.triFlags ? m.triFlags[prim] : m.defaultFlags;
+        const F3 p0 = f3(m.verts + 3 * (long)v0), p1 = f3(m.verts + 3 * (long)v1), p2 = f3(m.verts + 3 * (long)v2);
+        float uv[6] = {0, 0, 1, 0, 1, 1};  // shapes.h:898
+        if ((flags & NNBVH_TRI_HAS_UV) && m.uvs) {
+            uv[0] = m.uvs[2 * (long)v0], uv[1] = m.uvs[2 * (long)v0 + 1];
+            uv[2] = m.uvs[2 * (long)v1], uv[3] = m.uvs[2 * (long)v1 + 1];
+            uv[4] = m.uvs[2 * (long)v2], uv[5] = m.uvs[2 * (long)v2 + 1];
+        }
+        const float duv02x = uv[0] - uv[4], duv02y = uv[1] - uv[5];
+        const float duv12x = uv[2] - uv[4], duv12y = uv[3] - uv[5];
+        const F3 dp02 = p0 - p2, dp12 = p1 - p2;
+        const float determinant = dop(duv02x, duv12y, duv02y, duv12x);
+        F3 dpdu = {0, 0, 0}, dpdv = {0, 0, 0};
+        const bool degenerateUV = __builtin_fabsf(determinant) < 1e-9f;
+        if (!degenerateUV) {
+            const float invdet = 1 / determinant;
+            dpdu = scale(invdet, dop_v(duv12y, dp02, duv02y, dp12));
+            dpdv = scale(invdet, dop_v(duv02x, dp12, duv12x, dp02));
+        }
+        if (degenerateUV || len2(cross(dpdu, dpdv)) == 0) {
+            const F3 e20 = p2 - p0, e10 = p1 - p0;
+            F3 ng = cross(e20, e10);
+            if (len2(ng) == 0) {  // shapes.h:916-919: the cross product again, in double
+                const double vx = e20.x, vy = e20.y, vz = e20.z, wx = e10.x, wy = e10.y, wz = e10.z;
+                auto dopd = [](double a, double b, double c, double d) {
+                    const double cd = c * d;
+                    const double diff = __builtin_fma(a, b, -cd);
+                    const double err = __builtin_fma(-c, d, cd);
+                    return diff + err;
+                };
+                ng = {(float)dopd(vy, wz, vz, wy), (float)dopd(vz, wx, vx, wz), (float)dopd(vx, wy, vy, wx)};
+                // the reference CHECK-aborts on a zero normal here; IntersectTriangle never reports
+                // such a triangle as hit, so the record is simply marked for the host
+                if (len2(ng) == 0) {
+                    r.status = NNBVH_INTERACTION_HOST;
+                    out[i] = r;
+                    continue;
+                }
+            }
+            coordinate_system(normalize(ng), dpdu, dpdv);
+        }
+        const F3 pHit = bary(b0, b1, b2, p0, p1, p2);
+        const float uvHitU = (b0 * uv[0] + b1 * uv[2]) + b2 * uv[4];
+        const float uvHitV = (b0 * uv[1] + b1 * uv[3]) + b2 * uv[5];
+        const float g7 = gamma7();
+        const float pex = g7 * ((__builtin_fabsf(b0 * p0.x) + __builtin_fabsf(b1 * p1.x)) + __builtin_fabsf(b2 * p2.x));
+        const float pey = g7 * ((__builtin_fabsf(b0 * p0.y) + __builtin_fabsf(b1 * p1.y)) + __builtin_fabsf(b2 * p2.y));
+        const float pez = g7 * ((__builtin_fabsf(b0 * p0.z) + __builtin_fabsf(b1 * p1.z)) + __builtin_fabsf(b2 * p2.z));
+        // isect.n = isect.shading.n = Normalize(Cross(dp02, dp12)), flipped by orientation (:933-936)
+        F3 nrm = normalize(cross(dp02, dp12));
+        if (flags & NNBVH_TRI_FLIP_NORMAL) nrm = neg(nrm);
+        F3 ns = nrm, sdpdu = dpdu, sdpdv = dpdv, dndu = {0, 0, 0}, dndv = {0, 0, 0};
+        const bool hasN = (flags & NNBVH_TRI_HAS_N) && m.normals, hasS = (flags & NNBVH_TRI_HAS_S) && m.tangents;
+        if (hasN || hasS) {
+            F3 n0 = {0, 0, 0}, n1 = n0, n2 = n0;
+            F3 nsv = nrm;
+            if (hasN) {
+                n0 = f3(m.normals + 3 * (long)v0), n1 = f3(m.normals + 3 * (long)v1), n2 = f3(m.normals + 3 * (long)v2);
+                const F3 t = bary(b0, b1, b2, n0, n1, n2);
+                if (len2(t) > 0) nsv = normalize(t);
+            }
+            F3 ss = dpdu;
+            if (hasS) {
+                const F3 t = bary(b0, b1, b2, f3(m.tangents + 3 * (long)v0), f3(m.tangents + 3 * (long)v1),
+                                  f3(m.tangents + 3 * (long)v2));
+                if (len2(t) != 0) ss = t;
+            }
+            F3 ts = cross(nsv, ss);
+            if (len2(ts) > 0) ss = cross(ts, nsv);
+            else coordinate_system(nsv, ss, ts);
+            if (hasN) {
+                const F3 dn1 = n0 - n2, dn2 = n1 - n2;
+                const float det2 = dop(duv02x, duv12y, duv02y, duv12x);
+                if ((double)__builtin_fabsf(det2) < 1e-9) {  // :963 compares against a double literal
+                    const F3 dn = cross(n2 - n0, n1 - n0);
+                    if (len2(dn) != 0) coordinate_system(dn, dndu, dndv);
+                } else {
+                    const float invDet = 1 / det2;
+                    dndu = scale(invDet, dop_v(duv12y, dn1, duv02y, dn2));
+                    dndv = scale(invDet, dop_v(duv02x, dn2, duv12x, dn1));
+                }
+            }
+            // SetShadingGeometry(ns, ss, ts, dndu, dndv, true): interaction.h:194-214
+            ns = nsv;
+            if (dot_n(nrm, ns) < 0.f) nrm = neg(nrm);
+            sdpdu = ss;
+            sdpdv = ts;
+            while (len2(sdpdu) > 1e16f || len2(sdpdv) > 1e16f) {
+                sdpdu = {sdpdu.x / 1e8f, sdpdu.y / 1e8f, sdpdu.z / 1e8f};
+                sdpdv = {sdpdv.x / 1e8f, sdpdv.y / 1e8f, sdpdv.z / 1e8f};
+            }
+        }
+        const float ph[3] = {pHit.x, pHit.y, pHit.z}, pe[3] = {pex, pey, pez};
+        for (int k = 0; k < 3; ++k) {  // Point3fi(pHit, pError): vecmath.h:751-754
+            if (pe[k] == 0) {
+                r.pi_lo[k] = r.pi_hi[k] = ph[k];
+            } else {
+                r.pi_lo[k] = next_down(ph[k] + (-pe[k]));
+                r.pi_hi[k] = next_up(ph[k] + pe[k]);
+            }
+        }
+        const F3 won = normalize(wo);  // Interaction(): wo(Normalize(wo)), interaction.h:32-33
+        r.uv[0] = uvHitU, r.uv[1] = uvHitV;
+        r.wo[0] = won.x, r.wo[1] = won.y, r.wo[2] = won.z;
+        r.time = time;
+        r.n[0] = nrm.x, r.n[1] = nrm.y, r.n[2] = nrm.z;
+        r.face_index = m.faceIndices ? m.faceIndices[prim] : 0;
+        r.dpdu[0] = dpdu.x, r.dpdu[1] = dpdu.y, r.dpdu[2] = dpdu.z;
+        r.dpdv[0] = dpdv.x, r.dpdv[1] = dpdv.y, r.dpdv[2] = dpdv.z;
+        r.ns[0] = ns.x, r.ns[1] = ns.y, r.ns[2] = ns.z;
+        r.dpdus[0] = sdpdu.x, r.dpdus[1] = sdpdu.y, r.dpdus[2] = sdpdu.z;
+        r.dpdvs[0] = sdpdv.x, r.dpdvs[1] = sdpdv.y, r.dpdvs[2] = sdpdv.z;
+        r.dndus[0] = dndu.x, r.dndus[1] = dndu.y, r.dndus[2] = dndu.z;
+        r.dndvs[0] = dndv.x, r.dndvs[1] = dndv.y, r.dndvs[2] = dndv.z;
+        out[i] = r;
+    }
+}
+
+hipError_t launch_triangle_interactions(const ShadingMeshDevice &m, const void *rays, const nnbvh_ray_soa *soa,
+                                        const void *hits, int n, const int32_t *nDev, void *out, int maxBlocks,
+                                        hipStream_t stream) {
+    MeshView v{m.verts, m.triVerts, m.normals, m.uvs, m.tangents, m.faceIndices, m.triFlags, m.nTris, m.defaultFlags};
+    nnbvh_ray_soa s;
+    __builtin_memset(&s, 0, sizeof s);
+    if (soa) s = *soa;
+    int blocks = (n + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks < maxBlocks ? blocks : maxBlocks);
+    hipLaunchKernelGGL(k_triangle_interactions, dim3(blocks), dim3(256), 0, stream, v, (const float4 *)rays, s,
+                       (const float4 *)hits, n, nDev, (nnbvh_interaction *)out);
+    return hipGetLastError();
+}
+
+}  // namespace nnbvh

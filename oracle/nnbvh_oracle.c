@@ -819,3 +819,232 @@ void orc_record_shadow(const uint8_t *occluded, int n, const float *Ld, const fl
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Triangle::InteractionFromIntersection (shapes.h:884-1010) + the SurfaceInteraction constructor
+ * and SetShadingGeometry it runs (interaction.h:164-214).  Output record (44 floats):
+ *   [0..2] p() = interval midpoints, [3..5] pi.Error(), [6..7] uv, [8..10] wo, [11..13] n,
+ *   [14..16] dpdu, [17..19] dpdv, [20..22] shading.n, [23..25] shading.dpdu, [26..28] shading.dpdv,
+ *   [29..31] shading.dndu, [32..34] shading.dndv, [35] time, [36] faceIndex, [37] 0,
+ *   [38..40] pi lower bounds, [41..43] pi upper bounds.
+ * uv6 / n9 / s9 may be NULL (mesh without that attribute).  Returns 0 when the reference would
+ * CHECK-abort (zero-area triangle, which IntersectTriangle never reports as hit). */
+static inline void orc_dop_v(float a, const float b[3], float c, const float d[3], float out[3]) {
+    /* DifferenceOfProducts(Float, Vector3f, Float, Vector3f): math.h:569-575 with the
+     * component-wise vector FMA of vecmath.h:415-417 */
+    for (int k = 0; k < 3; ++k) {
+        float cd = c * d[k];
+        float diff = fmaf(a, b[k], -cd);
+        float err = fmaf(-c, d[k], cd);
+        out[k] = diff + err;
+    }
+}
+static inline float orc_sop(float a, float b, float c, float d) { /* SumOfProducts, math.h:577-583 */
+    float cd = c * d;
+    float s = fmaf(a, b, cd);
+    float err = fmaf(c, d, -cd);
+    return s + err;
+}
+static inline float orc_dot_n(const float n[3], const float v[3]) { /* Dot(Normal3, .), vecmath.h:1056-1075 */
+    return fmaf(n[0], v[0], orc_sop(n[1], v[1], n[2], v[2]));
+}
+static inline void orc_normalize(const float v[3], float out[3]) { /* v / Length(v), vecmath.h:953-961 */
+    float len = sqrtf(orc_len2(v));
+    for (int k = 0; k < 3; ++k) out[k] = v[k] / len;
+}
+static inline void orc_coordinate_system(const float v1[3], float v2[3], float v3[3]) { /* vecmath.h:1007-1013 */
+    float sign = copysignf(1.0f, v1[2]);
+    float a = -1 / (sign + v1[2]);
+    float b = v1[0] * v1[1] * a;
+    v2[0] = 1 + sign * (v1[0] * v1[0]) * a;
+    v2[1] = sign * b;
+    v2[2] = -sign * v1[0];
+    v3[0] = b;
+    v3[1] = sign + (v1[1] * v1[1]) * a;
+    v3[2] = -v1[1];
+}
+static inline void orc_bary3(const float b[3], const float *a0, const float *a1, const float *a2, int dim,
+                             float *out) { /* b0 * a0 + b1 * a1 + b2 * a2, left to right */
+    for (int k = 0; k < dim; ++k) out[k] = (b[0] * a0[k] + b[1] * a1[k]) + b[2] * a2[k];
+}
+
+/* how often each rare branch was taken (tests check that the vectors reach them):
+ * 0 degenerate uv, 1 dpdu x dpdv == 0, 2 zero interpolated normal, 3 zero tangent, 4 tangent
+ * parallel to normal, 5 degenerate uv in the dndu/dndv block, 6 equal normals (dn == 0),
+ * 7 shading dpdu rescaled, 8 geometric normal flipped to the shading side */
+long orc_interaction_branches[9];
+
+int orc_triangle_interaction(const float p9[9], const float *uv6, const float *n9, const float *s9,
+                             int flip_normal, const float b[3], const float wo[3], float time,
+                             int face_index, float out[44]) {
+    const float *p0 = p9, *p1 = p9 + 3, *p2 = p9 + 6;
+    static const float uv_default[6] = {0, 0, 1, 0, 1, 1};
+    const float *uv = uv6 ? uv6 : uv_default;
+    float duv02[2] = {uv[0] - uv[4], uv[1] - uv[5]}, duv12[2] = {uv[2] - uv[4], uv[3] - uv[5]};
+    float dp02[3], dp12[3];
+    for (int k = 0; k < 3; ++k) {
+        dp02[k] = p0[k] - p2[k];
+        dp12[k] = p1[k] - p2[k];
+    }
+    float determinant = orc_dop(duv02[0], duv12[1], duv02[1], duv12[0]);
+    float dpdu[3] = {0, 0, 0}, dpdv[3] = {0, 0, 0};
+    int degenerate_uv = fabsf(determinant) < 1e-9f;
+    if (!degenerate_uv) {
+        float invdet = 1 / determinant, t[3];
+        orc_dop_v(duv12[1], dp02, duv02[1], dp12, t);
+        for (int k = 0; k < 3; ++k) dpdu[k] = invdet * t[k];
+        orc_dop_v(duv02[0], dp12, duv12[0], dp02, t);
+        for (int k = 0; k < 3; ++k) dpdv[k] = invdet * t[k];
+    }
+    float c[3];
+    orc_cross(dpdu, dpdv, c);
+    if (degenerate_uv) ++orc_interaction_branches[0];
+    else if (orc_len2(c) == 0) ++orc_interaction_branches[1];
+    if (degenerate_uv || orc_len2(c) == 0) {
+        float e20[3], e10[3], ng[3], ngn[3];
+        for (int k = 0; k < 3; ++k) {
+            e20[k] = p2[k] - p0[k];
+            e10[k] = p1[k] - p0[k];
+        }
+        orc_cross(e20, e10, ng);
+        if (orc_len2(ng) == 0) { /* shapes.h:916-919: redo the cross product in double */
+            double v[3] = {e20[0], e20[1], e20[2]}, w[3] = {e10[0], e10[1], e10[2]}, r[3];
+            for (int k = 0; k < 3; ++k) {
+                int i1 = (k + 1) % 3, i2 = (k + 2) % 3;
+                double cd = v[i2] * w[i1];
+                double diff = fma(v[i1], w[i2], -cd);
+                double err = fma(-v[i2], w[i1], cd);
+                r[k] = diff + err;
+            }
+            for (int k = 0; k < 3; ++k) ng[k] = (float)r[k];
+            if (orc_len2(ng) == 0) return 0;
+        }
+        orc_normalize(ng, ngn);
+        orc_coordinate_system(ngn, dpdu, dpdv);
+    }
+    float p_hit[3], uv_hit[2], p_err[3];
+    orc_bary3(b, p0, p1, p2, 3, p_hit);
+    orc_bary3(b, uv, uv + 2, uv + 4, 2, uv_hit);
+    for (int k = 0; k < 3; ++k) {
+        float s = (fabsf(b[0] * p0[k]) + fabsf(b[1] * p1[k])) + fabsf(b[2] * p2[k]);
+        p_err[k] = orc_gamma(7) * s;
+    }
+    /* isect.n = isect.shading.n = Normalize(Cross(dp02, dp12)), flipped by orientation (:933-936);
+     * the constructor's own n (from dpdu x dpdv) is overwritten */
+    float n[3], ns[3], t[3];
+    orc_cross(dp02, dp12, t);
+    orc_normalize(t, n);
+    if (flip_normal)
+        for (int k = 0; k < 3; ++k) n[k] = -n[k];
+    float sdpdu[3], sdpdv[3], dndu[3] = {0, 0, 0}, dndv[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        ns[k] = n[k];
+        sdpdu[k] = dpdu[k];
+        sdpdv[k] = dpdv[k];
+    }
+    if (n9 || s9) {
+        float nsv[3], ss[3], ts[3];
+        if (n9) {
+            orc_bary3(b, n9, n9 + 3, n9 + 6, 3, t);
+            if (orc_len2(t) > 0) orc_normalize(t, nsv);
+            else {
+                memcpy(nsv, n, 12);
+                ++orc_interaction_branches[2];
+            }
+        } else
+            memcpy(nsv, n, 12);
+        if (s9) {
+            orc_bary3(b, s9, s9 + 3, s9 + 6, 3, ss);
+            if (orc_len2(ss) == 0) {
+                memcpy(ss, dpdu, 12);
+                ++orc_interaction_branches[3];
+            }
+        } else
+            memcpy(ss, dpdu, 12);
+        orc_cross(nsv, ss, ts);
+        if (orc_len2(ts) > 0) orc_cross(ts, nsv, ss);
+        else {
+            orc_coordinate_system(nsv, ss, ts);
+            ++orc_interaction_branches[4];
+        }
+        if (n9) {
+            float dn1[3], dn2[3];
+            for (int k = 0; k < 3; ++k) {
+                dn1[k] = n9[k] - n9[6 + k];
+                dn2[k] = n9[3 + k] - n9[6 + k];
+            }
+            float det2 = orc_dop(duv02[0], duv12[1], duv02[1], duv12[0]);
+            int degenerate2 = (double)fabsf(det2) < 1e-9; /* :963: a double literal here */
+            if (degenerate2) {
+                float a[3], bb[3], dn[3];
+                ++orc_interaction_branches[5];
+                for (int k = 0; k < 3; ++k) {
+                    a[k] = n9[6 + k] - n9[k];
+                    bb[k] = n9[3 + k] - n9[k];
+                }
+                orc_cross(a, bb, dn);
+                if (orc_len2(dn) != 0) orc_coordinate_system(dn, dndu, dndv);
+                else ++orc_interaction_branches[6];
+            } else {
+                float inv_det = 1 / det2;
+                orc_dop_v(duv12[1], dn1, duv02[1], dn2, t);
+                for (int k = 0; k < 3; ++k) dndu[k] = inv_det * t[k];
+                orc_dop_v(duv02[0], dn2, duv12[0], dn1, t);
+                for (int k = 0; k < 3; ++k) dndv[k] = inv_det * t[k];
+            }
+        }
+        /* SetShadingGeometry(ns, ss, ts, dndu, dndv, true): interaction.h:194-214 */
+        memcpy(ns, nsv, 12);
+        if (orc_dot_n(n, ns) < 0.f) {
+            for (int k = 0; k < 3; ++k) n[k] = -n[k];
+            ++orc_interaction_branches[8];
+        }
+        memcpy(sdpdu, ss, 12);
+        memcpy(sdpdv, ts, 12);
+        while (orc_len2(sdpdu) > 1e16f || orc_len2(sdpdv) > 1e16f) {
+            ++orc_interaction_branches[7];
+            for (int k = 0; k < 3; ++k) {
+                sdpdu[k] /= 1e8f;
+                sdpdv[k] /= 1e8f;
+            }
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        orc_ivl iv = ivl_from_value_and_error(p_hit[k], p_err[k]);
+        out[k] = (iv.lo + iv.hi) / 2;
+        out[3 + k] = (iv.hi - iv.lo) / 2;
+        out[38 + k] = iv.lo;
+        out[41 + k] = iv.hi;
+        out[11 + k] = n[k];
+        out[14 + k] = dpdu[k];
+        out[17 + k] = dpdv[k];
+        out[20 + k] = ns[k];
+        out[23 + k] = sdpdu[k];
+        out[26 + k] = sdpdv[k];
+        out[29 + k] = dndu[k];
+        out[32 + k] = dndv[k];
+    }
+    orc_normalize(wo, out + 8); /* Interaction(): wo(Normalize(wo)), interaction.h:32-33 */
+    out[6] = uv_hit[0];
+    out[7] = uv_hit[1];
+    out[35] = time;
+    out[36] = (float)face_index;
+    out[37] = 0;
+    return 1;
+}
+
+/* records as oracle/ref_interaction.cpp reads them (45 floats, see there).  That harness builds its
+ * mesh with the reference's TriangleMesh constructor, which stores the normals NEGATED when
+ * reverseOrientation is set (util/mesh.cpp:52-58); the same is done to the input here, so that
+ * orc_triangle_interaction sees mesh->n as InteractionFromIntersection does. */
+void orc_triangle_interaction_batch(const float *in45, int n, float *out44) {
+    for (int i = 0; i < n; ++i) {
+        const float *r = in45 + 45 * (size_t)i;
+        int flags = (int)r[19];
+        float nn[9];
+        for (int k = 0; k < 9; ++k) nn[k] = (flags & 8) ? -r[26 + k] : r[26 + k];
+        orc_triangle_interaction(r, (flags & 1) ? r + 20 : NULL, (flags & 2) ? nn : NULL,
+                                 (flags & 4) ? r + 36 : NULL, (flags & 8) != 0, r + 9, r + 12, r[18], 7 + i,
+                                 out44 + 44 * (size_t)i);
+    }
+}

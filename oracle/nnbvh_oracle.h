@@ -115,6 +115,13 @@ void orc_wavefront_enqueue_closest(const orc_hit *hits, int n, const uint8_t *ha
 void orc_record_shadow(const uint8_t *occluded, int n, const float *Ld, const float *r_u,
                        const float *r_l, const int32_t *pixel_index, float *L);
 
+/* Triangle::InteractionFromIntersection (shapes.h:884-1010): 44-float record, layout in the .c;
+ * uv6 / n9 / s9 NULL = mesh without that attribute */
+int orc_triangle_interaction(const float p9[9], const float *uv6, const float *n9, const float *s9,
+                             int flip_normal, const float b[3], const float wo[3], float time,
+                             int face_index, float out[44]);
+void orc_triangle_interaction_batch(const float *in45, int n, float *out44);
+
 /* brute force closest hit over all prims in index order (no BVH): a second,
  * tree-independent check of t for the traversal restatement. */
 void orc_brute_closest(const orc_prim *prims, int n_prims, const float *verts,

@@ -1,0 +1,77 @@
+// ref_interaction.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// Batch driver around the REFERENCE's own Triangle::InteractionFromIntersection
+// (/root/reference/src/pbrt/shapes.h:884-1010, inline) on a one-triangle TriangleMesh built by
+// the reference's own constructor (src/pbrt/util/mesh.cpp:23-77, identity transform).  No restated
+// arithmetic.  Built by oracle/Makefile into oracle/_ref/ref_interaction (git-ignored); used to
+// validate oracle/nnbvh_oracle.c's orc_triangle_interaction and to generate
+// tests/golden/tri_interaction.npz (tests/golden/make_interaction_golden.py).
+//
+// usage: ref_interaction <in.bin> <out.bin>
+//   in.bin : int32 n, then n records of 36 float32:
+//            p0[3] p1[3] p2[3]  b0 b1 b2  wo[3]  time  flags  uv0[2] uv1[2] uv2[2]  n0[3] n1[3] n2[3]  s0? -> see below
+//            flags bit 0: mesh has uv, bit 1: mesh has n, bit 2: mesh has s, bit 3: reverseOrientation
+//            (36 floats = 9 + 3 + 3 + 1 + 1 + 6 + 9 + 4 pad; tangents s0..s2 follow as 9 more = 45)
+//   out.bin: n records of 38 float32: p[3] pError[3] uv[2] wo[3] n[3] dpdu[3] dpdv[3]
+//            ns[3] dpdus[3] dpdvs[3] dndus[3] dndvs[3] time faceIndex(as float)
+#include <pbrt/pbrt.h>
+#include <pbrt/interaction.h>
+#include <pbrt/options.h>
+#include <pbrt/shapes.h>
+#include <pbrt/util/buffercache.h>
+#include <pbrt/util/mesh.h>
+#include <pbrt/util/transform.h>
+#include <pbrt/util/vecmath.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+using namespace pbrt;
+
+static constexpr int kIn = 45, kOut = 38;
+
+int main(int argc, char **argv) {
+    if (argc != 3) return 2;
+    FILE *fi = std::fopen(argv[1], "rb");
+    FILE *fo = std::fopen(argv[2], "wb");
+    if (!fi || !fo) return 3;
+    int32_t n = 0;
+    if (std::fread(&n, 4, 1, fi) != 1) return 4;
+    std::vector<float> in((size_t)n * kIn);
+    if (std::fread(in.data(), 4, in.size(), fi) != in.size()) return 4;
+    Options = new PBRTOptions;
+    InitBufferCaches();
+    Allocator alloc;
+    for (int i = 0; i < n; ++i) {
+        const float *r = &in[(size_t)i * kIn];
+        const int flags = (int)r[19];
+        std::vector<Point3f> p = {Point3f(r[0], r[1], r[2]), Point3f(r[3], r[4], r[5]), Point3f(r[6], r[7], r[8])};
+        std::vector<Point2f> uv;
+        std::vector<Normal3f> N;
+        std::vector<Vector3f> S;
+        if (flags & 1) uv = {Point2f(r[20], r[21]), Point2f(r[22], r[23]), Point2f(r[24], r[25])};
+        if (flags & 2) N = {Normal3f(r[26], r[27], r[28]), Normal3f(r[29], r[30], r[31]), Normal3f(r[32], r[33], r[34])};
+        if (flags & 4) S = {Vector3f(r[36], r[37], r[38]), Vector3f(r[39], r[40], r[41]), Vector3f(r[42], r[43], r[44])};
+        TriangleMesh mesh(Transform(), (flags & 8) != 0, {0, 1, 2}, p, S, N, uv, {7 + i}, alloc);
+        TriangleIntersection ti{r[9], r[10], r[11], 1.f};
+        SurfaceInteraction si = Triangle::InteractionFromIntersection(&mesh, 0, ti, r[18], Vector3f(r[12], r[13], r[14]));
+        Point3f ph = si.p();
+        Vector3f pe = si.pi.Error();
+        float out[kOut] = {ph.x, ph.y, ph.z, pe.x, pe.y, pe.z, si.uv[0], si.uv[1], si.wo.x, si.wo.y, si.wo.z,
+                           si.n.x, si.n.y, si.n.z, si.dpdu.x, si.dpdu.y, si.dpdu.z, si.dpdv.x, si.dpdv.y, si.dpdv.z,
+                           si.shading.n.x, si.shading.n.y, si.shading.n.z,
+                           si.shading.dpdu.x, si.shading.dpdu.y, si.shading.dpdu.z,
+                           si.shading.dpdv.x, si.shading.dpdv.y, si.shading.dpdv.z,
+                           si.shading.dndu.x, si.shading.dndu.y, si.shading.dndu.z,
+                           si.shading.dndv.x, si.shading.dndv.y, si.shading.dndv.z,
+                           si.time, (float)si.faceIndex, 0.f};
+        // the exact interval as well: low/high of pi replace p/pError when asked for by tests
+        std::fwrite(out, 4, kOut, fo);
+        float iv[6] = {si.pi.x.LowerBound(), si.pi.y.LowerBound(), si.pi.z.LowerBound(),
+                       si.pi.x.UpperBound(), si.pi.y.UpperBound(), si.pi.z.UpperBound()};
+        std::fwrite(iv, 4, 6, fo);
+    }
+    std::fclose(fo);
+    return 0;
+}

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/tri_interaction.npz from the REFERENCE's own
+Triangle::InteractionFromIntersection (oracle/_ref/ref_interaction, built by oracle/Makefile from
+/root/reference sources).  Build-container only; the .npz holds data only: seeded inputs and the
+reference's outputs as float32 bit patterns."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_interaction")
+sys.path.insert(0, HERE)
+from interaction_cases import cases  # noqa: E402
+
+
+def run_ref(rec):
+    with tempfile.TemporaryDirectory() as td:
+        fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fi, "wb") as f:
+            f.write(np.int32(len(rec)).tobytes())
+            f.write(np.ascontiguousarray(rec, np.float32).tobytes())
+        subprocess.run([REF, fi, fo], check=True)
+        return np.fromfile(fo, dtype=np.uint32).reshape(len(rec), 44)
+
+
+if __name__ == "__main__":
+    rec = cases(4096, 20240607)
+    out = run_ref(rec)
+    np.savez_compressed(os.path.join(HERE, "tri_interaction.npz"), inputs=rec, outputs=out)
+    print("tri_interaction.npz:", rec.shape, out.shape)

@@ -162,3 +162,20 @@ def record_shadow(occluded, Ld, r_u, r_l, pixel_index, L):
     out = np.array(L, np.float32, copy=True)
     lib().orc_record_shadow(_p(occ), ctypes.c_int(len(occ)), _p(Ld), _p(r_u), _p(r_l), _p(px), _p(out))
     return out
+
+
+def triangle_interaction_batch(records45):
+    """orc_triangle_interaction_batch on oracle/ref_interaction.cpp-style records -> float32 [n, 44]."""
+    rec = np.ascontiguousarray(records45, np.float32).reshape(-1, 45)
+    out = np.zeros((len(rec), 44), np.float32)
+    lib().orc_triangle_interaction_batch(_p(rec), ctypes.c_int(len(rec)), _p(out))
+    return out
+
+
+def interaction_branches(reset=False):
+    arr = (ctypes.c_long * 9).in_dll(lib(), "orc_interaction_branches")
+    vals = list(arr)
+    if reset:
+        for k in range(9):
+            arr[k] = 0
+    return vals

@@ -1,0 +1,166 @@
+"""Hit record -> SurfaceInteraction (Triangle::InteractionFromIntersection, shapes.h:884-1010).
+
+CPU: the oracle's restatement against vectors produced by the REFERENCE's own compiled function
+(tests/golden/tri_interaction.npz, made by tests/golden/make_interaction_golden.py with
+oracle/_ref/ref_interaction) — every output word bit-equal — and, in the build container, against
+the reference binary live on fresh random inputs.  GPU: the HIP post-pass against the oracle,
+bit for bit, on the golden inputs and on hits traced through a small smooth-shaded mesh."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from interaction_cases import cases  # noqa: E402
+
+GOLDEN = os.path.join(HERE, "golden", "tri_interaction.npz")
+REF = os.path.join(HERE, "..", "oracle", "_ref", "ref_interaction")
+# record fields of the 44-float oracle / reference record
+FIELDS = {"uv": slice(6, 8), "wo": slice(8, 11), "n": slice(11, 14), "dpdu": slice(14, 17),
+          "dpdv": slice(17, 20), "ns": slice(20, 23), "dpdus": slice(23, 26), "dpdvs": slice(26, 29),
+          "dndus": slice(29, 32), "dndvs": slice(32, 35), "pi_lo": slice(38, 41), "pi_hi": slice(41, 44)}
+
+
+def test_oracle_matches_reference_vectors_bit_exact():
+    g = np.load(GOLDEN)
+    ob.interaction_branches(reset=True)
+    out = ob.triangle_interaction_batch(g["inputs"])
+    bad = np.nonzero(out.view(np.uint32) != g["outputs"])
+    assert len(bad[0]) == 0, f"{len(bad[0])} words differ, first rows {bad[0][:5]} cols {bad[1][:5]}"
+    # the vectors reach every rare branch of the function (see oracle/nnbvh_oracle.c)
+    assert min(ob.interaction_branches()) > 0, ob.interaction_branches()
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.isdir("/root/reference")),
+                    reason="compiled reference harness only exists in the build container")
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_oracle_equals_reference_live(seed):
+    rec = cases(20000, seed)
+    with tempfile.TemporaryDirectory() as td:
+        fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fi, "wb") as f:
+            f.write(np.int32(len(rec)).tobytes())
+            f.write(rec.tobytes())
+        subprocess.run([REF, fi, fo], check=True)
+        ref = np.fromfile(fo, dtype=np.uint32).reshape(len(rec), 44)
+    out = ob.triangle_interaction_batch(rec)
+    # faceIndex is 7 + record number in both
+    assert np.array_equal(out.view(np.uint32), ref)
+
+
+def mesh_from_records(rec):
+    """One triangle with three private vertices per record; attributes as TriangleMesh stores them."""
+    from nn_bvh_amd import _lib
+    n = len(rec)
+    flags_in = rec[:, 19].astype(np.int32)
+    verts = rec[:, 0:9].reshape(-1, 3)
+    uvs = rec[:, 20:26].reshape(-1, 2)
+    normals = rec[:, 26:35].reshape(-1, 3).copy()
+    normals[np.repeat((flags_in & 8) != 0, 3)] *= -1  # util/mesh.cpp:52-58
+    tangents = rec[:, 36:45].reshape(-1, 3)
+    tri_flags = (((flags_in & 1) != 0) * _lib.TRI_HAS_UV + ((flags_in & 2) != 0) * _lib.TRI_HAS_N +
+                 ((flags_in & 4) != 0) * _lib.TRI_HAS_S + ((flags_in & 8) != 0) * _lib.TRI_FLIP_NORMAL)
+    return dict(verts=verts, tri_vertices=np.arange(3 * n, dtype=np.int32).reshape(n, 3), normals=normals,
+                uvs=uvs, tangents=tangents, face_indices=7 + np.arange(n, dtype=np.int32),
+                tri_flags=tri_flags.astype(np.uint8))
+
+
+def assert_records_equal(got, exp44, rows, what):
+    for name, sl in FIELDS.items():
+        a = np.ascontiguousarray(got[name][rows]).view(np.uint32).reshape(len(rows), -1)
+        b = np.ascontiguousarray(exp44[rows][:, sl]).view(np.uint32)
+        bad = np.nonzero((a != b).any(1))[0]
+        assert len(bad) == 0, f"{what}: {name} differs on {len(bad)} records, first {rows[bad[:5]]}"
+    assert np.array_equal(got["time"][rows].view(np.uint32), exp44[rows, 35].view(np.uint32)), what
+    assert np.array_equal(got["face_index"][rows], exp44[rows, 36].astype(np.int32)), what
+
+
+@pytest.mark.gpu
+def test_gpu_interactions_match_oracle_on_reference_vectors():
+    from nn_bvh_amd import HIT_DTYPE, RAY_DTYPE
+    from nn_bvh_amd.interaction import ShadingMesh
+    rec = np.load(GOLDEN)["inputs"]
+    n = len(rec)
+    exp = ob.triangle_interaction_batch(rec)
+    mesh = ShadingMesh(**mesh_from_records(rec))
+    hits = np.zeros(n, HIT_DTYPE)
+    hits["prim"] = np.arange(n)
+    hits["b0"], hits["b1"], hits["b2"] = rec[:, 9], rec[:, 10], rec[:, 11]
+    hits["t"] = 1.0
+    rays = np.zeros(n, RAY_DTYPE)
+    rays["d"] = -rec[:, 12:15]
+    rays["time"] = rec[:, 18]
+    got = mesh.interactions(rays, hits)
+    assert (got["status"] == 1).all() and np.array_equal(got["prim"], hits["prim"])
+    assert_records_equal(got, exp, np.arange(n), "golden inputs")
+    mesh.close()
+
+
+@pytest.mark.gpu
+def test_gpu_interactions_of_traced_hits_soa_queue_and_statuses():
+    import torch
+    import scenes_small as ss
+    from nn_bvh_amd import BVHAggregate, HIT_DTYPE, _lib, build_tree, scene
+    from nn_bvh_amd.interaction import ShadingMesh
+    from nn_bvh_amd.wavefront import RayQueue, WavefrontAggregate
+    verts, prims = ss.grid_mesh(40, 3)
+    patch_v, patch_p = ss.random_soup(0, 60, 5)
+    patch_p = patch_p.copy()
+    patch_p["v"] += len(verts)
+    patch_p["id"] += len(prims)
+    allv, allp = np.concatenate([verts, patch_v]), np.concatenate([prims, patch_p])
+    rng = np.random.default_rng(2)
+    normals = rng.normal(size=(len(allv), 3)).astype(np.float32)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    uvs = rng.random((len(allv), 2)).astype(np.float32)
+    tri_vertices = np.full((len(allp), 3), -1, np.int32)
+    tri_vertices[allp["id"][allp["kind"] == 0]] = allp["v"][allp["kind"] == 0][:, :3]
+    mesh = ShadingMesh(allv, tri_vertices, normals=normals, uvs=uvs)
+    tree = build_tree(allp, allv)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, allv)
+    n = 20000
+    rays = scene.random_rays(n, allv.min(0) - 2, allv.max(0) + 2, 7)
+    rays["time"] = rng.random(n).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    rq = RayQueue.from_records(rays, dev)
+    rq.time = torch.from_numpy(np.ascontiguousarray(rays["time"])).to(dev)
+    size = n - 123
+    rq.size.fill_(size)
+    hits_t = WavefrontAggregate(agg).IntersectClosest(n, rq)
+    out = torch.full((n * 160,), 0x5A, dtype=torch.uint8, device=dev)
+    mesh.interactions_device(hits_t.data_ptr(), n, out.data_ptr(), ray_queue=rq, d_size=rq.size.data_ptr(),
+                             stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(_lib.INTERACTION_DTYPE)
+    hits = hits_t.cpu().numpy().view(HIT_DTYPE).reshape(-1)[:size]
+    assert (out.cpu().numpy()[size * 160:] == 0x5A).all(), "records beyond the queue size were written"
+    is_tri = (hits["prim"] >= 0) & (hits["prim"] < len(prims))
+    is_patch = hits["prim"] >= len(prims)
+    assert is_tri.sum() > 1000 and is_patch.sum() > 10 and (hits["prim"] < 0).sum() > 1000
+    assert (got["status"][:size][hits["prim"] < 0] == 0).all()
+    assert (got["status"][:size][is_patch] == 2).all()
+    assert (got["status"][:size][is_tri] == 1).all()
+    # oracle records for the triangle hits
+    rows = np.nonzero(is_tri)[0]
+    rec = np.zeros((len(rows), 45), np.float32)
+    tv = tri_vertices[hits["prim"][rows]]
+    rec[:, 0:9] = allv[tv].reshape(-1, 9)
+    rec[:, 9], rec[:, 10], rec[:, 11] = hits["b0"][rows], hits["b1"][rows], hits["b2"][rows]
+    rec[:, 12:15] = -rays["d"][rows]
+    rec[:, 18] = rays["time"][rows]
+    rec[:, 19] = 3
+    rec[:, 20:26] = uvs[tv].reshape(-1, 6)
+    rec[:, 26:35] = normals[tv].reshape(-1, 9)
+    exp = ob.triangle_interaction_batch(rec)
+    exp[:, 36] = 0  # no faceIndices array: faceIndex 0
+    full = np.zeros((size, 44), np.float32)
+    full[rows] = exp
+    assert_records_equal(got[:size], full, rows, "traced hits")
+    agg.close()
+    mesh.close()
