@@ -278,7 +278,7 @@ nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
 void nnbvh_shading_mesh_destroy(nnbvh_shading_mesh *m);
 
 #define NNBVH_INTERACTION_MISS 0
-#define NNBVH_INTERACTION_TRIANGLE 1 /* fields below are valid */
+#define NNBVH_INTERACTION_TRIANGLE 1 /* all fields valid; otherwise only prim and status are written */
 #define NNBVH_INTERACTION_HOST 2     /* hit on a bilinear patch, inside an instance or on a host
                                         primitive: the caller finishes it on the host */
 typedef struct nnbvh_interaction {   /* 160 B */
@@ -297,6 +297,9 @@ typedef struct nnbvh_interaction {   /* 160 B */
 /* One of d_rays (nnbvh_ray[max_items]) / ray_soa gives the rays the hits belong to (direction and
  * time are read).  n = min(max_items, *d_size) when d_size != NULL.  d_out: nnbvh_interaction
  * [max_items], record i for hit i. */
+/* host buffers (synchronous; copies in and out, like nnbvh_intersect_closest) */
+int nnbvh_triangle_interactions(const nnbvh_shading_mesh *m, const nnbvh_ray *rays, const nnbvh_hit *hits,
+                                int32_t n, nnbvh_interaction *out);
 int nnbvh_triangle_interactions_device(const nnbvh_shading_mesh *m, const void *d_rays,
                                        const nnbvh_ray_soa *ray_soa, const void *d_hits,
                                        int32_t max_items, const int32_t *d_size, void *d_out,

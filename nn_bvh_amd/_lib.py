@@ -48,6 +48,7 @@ EXPORTS = [
     "nnbvh_build_create_with_bounds", "nnbvh_wavefront_intersect_closest",
     "nnbvh_wavefront_intersect_shadow", "nnbvh_build_create_gpu", "nnbvh_build_gpu_timing",
     "nnbvh_shading_mesh_create", "nnbvh_shading_mesh_destroy", "nnbvh_triangle_interactions_device",
+    "nnbvh_triangle_interactions",
 ]
 
 _lib = None
@@ -66,6 +67,13 @@ def lib():
         raise NNBVHError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the traversal path has no fallback)")
+    # A process must hold ONE HIP runtime.  PyTorch (used for device buffers by the callers of the
+    # *_device entry points) ships its own libamdhip64; if this library pulled in the system copy
+    # first, torch.cuda would later find no device.  Loading torch first makes both share torch's.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     L.nnbvh_last_error.restype = ctypes.c_char_p
@@ -114,6 +122,8 @@ def lib():
     L.nnbvh_shading_mesh_create.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32]
     L.nnbvh_shading_mesh_destroy.restype = None
     L.nnbvh_shading_mesh_destroy.argtypes = [vp]
+    L.nnbvh_triangle_interactions.restype = i32
+    L.nnbvh_triangle_interactions.argtypes = [vp, vp, vp, i32, vp]
     L.nnbvh_triangle_interactions_device.restype = i32
     L.nnbvh_triangle_interactions_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     L.nnbvh_wavefront_intersect_closest.restype = i32

@@ -872,6 +872,31 @@ int nnbvh_triangle_interactions_device(const nnbvh_shading_mesh *m, const void *
     return NNBVH_OK;
 }
 
+int nnbvh_triangle_interactions(const nnbvh_shading_mesh *m, const nnbvh_ray *rays, const nnbvh_hit *hits,
+                                int32_t n, nnbvh_interaction *out) {
+    if (!m || n < 0 || (n > 0 && (!rays || !hits || !out))) {
+        set_error("triangle_interactions: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    if (n == 0) return NNBVH_OK;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    void *d_rays = nullptr, *d_hits = nullptr, *d_out = nullptr;
+    int rc = NNBVH_ERR_DEVICE;
+    if (hip_ok(hipMalloc(&d_rays, (size_t)n * sizeof(nnbvh_ray)), "hipMalloc(rays)") &&
+        hip_ok(hipMalloc(&d_hits, (size_t)n * sizeof(nnbvh_hit)), "hipMalloc(hits)") &&
+        hip_ok(hipMalloc(&d_out, (size_t)n * sizeof(nnbvh_interaction)), "hipMalloc(interactions)") &&
+        hip_ok(hipMemcpy(d_rays, rays, (size_t)n * sizeof(nnbvh_ray), hipMemcpyHostToDevice), "copy rays") &&
+        hip_ok(hipMemcpy(d_hits, hits, (size_t)n * sizeof(nnbvh_hit), hipMemcpyHostToDevice), "copy hits") &&
+        hip_ok(launch_triangle_interactions(m->d, d_rays, nullptr, d_hits, n, nullptr, d_out, m->n_cus * 8, nullptr),
+               "interaction kernel launch") &&
+        hip_ok(hipMemcpy(out, d_out, (size_t)n * sizeof(nnbvh_interaction), hipMemcpyDeviceToHost), "copy interactions"))
+        rc = NNBVH_OK;
+    for (void *p : {d_rays, d_hits, d_out})
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
 int nnbvh_intersect_closest(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits) {
     if (!s || n < 0 || (n > 0 && (!rays || !hits))) {
         set_error("intersect_closest: bad argument");

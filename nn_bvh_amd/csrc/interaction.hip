@@ -116,7 +116,9 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
             r.status = hostCase ? NNBVH_INTERACTION_HOST : NNBVH_INTERACTION_TRIANGLE;
         }
         if (r.status != NNBVH_INTERACTION_TRIANGLE) {
-            out[i] = r;
+            // only prim / status are meaningful: store the record's last 16 B {dndvs.z, prim, status, pad}
+            reinterpret_cast<float4 *>(out + i)[9] =
+                make_float4(0.0f, __int_as_float(prim), __int_as_float(r.status), 0.0f);
             continue;
         }
         F3 wo;
@@ -166,8 +168,8 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
                 // the reference CHECK-aborts on a zero normal here; IntersectTriangle never reports
                 // such a triangle as hit, so the record is simply marked for the host
                 if (len2(ng) == 0) {
-                    r.status = NNBVH_INTERACTION_HOST;
-                    out[i] = r;
+                    reinterpret_cast<float4 *>(out + i)[9] =
+                        make_float4(0.0f, __int_as_float(prim), __int_as_float(NNBVH_INTERACTION_HOST), 0.0f);
                     continue;
                 }
             }

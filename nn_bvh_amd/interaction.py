@@ -50,12 +50,9 @@ class ShadingMesh:
 
     def interactions(self, rays, hits):
         """Host arrays in (RAY_DTYPE, HIT_DTYPE), INTERACTION_DTYPE records out."""
-        import torch
-        dev = torch.device("cuda", self.device)
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)  # noqa: E731
-        d_rays, d_hits = up(rays), up(hits)
-        out = torch.empty(len(hits) * INTERACTION_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-        self.interactions_device(d_hits.data_ptr(), len(hits), out.data_ptr(), d_rays=d_rays.data_ptr(),
-                                 stream=torch.cuda.current_stream(dev).cuda_stream)
-        torch.cuda.synchronize(dev)
-        return out.cpu().numpy().view(INTERACTION_DTYPE)
+        rays = np.ascontiguousarray(rays, _lib.RAY_DTYPE)
+        hits = np.ascontiguousarray(hits, _lib.HIT_DTYPE)
+        out = np.zeros(len(hits), INTERACTION_DTYPE)
+        check(_lib.lib().nnbvh_triangle_interactions(self._h, ptr(rays), ptr(hits), len(hits), ptr(out)),
+              "nnbvh_triangle_interactions")
+        return out
