@@ -4,8 +4,9 @@ crown scene's six area-light quads, every stage device-resident.
 
   camera rays (SOA RayQueue)
     -> WavefrontAggregate.IntersectClosest       hit records + escaped / material index queues
-    -> "material stage" (a few torch ops over the material queue: geometric normal, light sample,
-       unoccluded contribution Ld, shadow ray)   -> ShadowRayQueue
+    -> ShadingMesh.interactions_device           SurfaceInteraction records (p, n, ...) per hit
+    -> "material stage" (a few torch ops over the material queue: light sample, unoccluded
+       contribution Ld, shadow ray)              -> ShadowRayQueue
     -> WavefrontAggregate.IntersectShadow        L[pixel] += Ld / (r_u + r_l).Average() if visible
     -> film: mean over samples, tone map, PNG (zlib only)
 
@@ -46,6 +47,7 @@ def main():
     args = ap.parse_args()
     import torch
     from nn_bvh_amd import BVHAggregate, build_tree, make_prims, scene
+    from nn_bvh_amd.interaction import ShadingMesh
     from nn_bvh_amd.wavefront import RayQueue, WavefrontAggregate, WorkQueue
 
     dev = torch.device("cuda", 0)
@@ -55,8 +57,7 @@ def main():
     wf = WavefrontAggregate(agg)
     cam = args.scene if args.scene in scene.CAMERAS else "crown"
     xres, yres = scene.CAMERAS[cam][4] // args.scale, scene.CAMERAS[cam][5] // args.scale
-    d_verts = torch.from_numpy(verts).to(dev)
-    d_tris = torch.from_numpy(tris.astype(np.int64)).to(dev)
+    smesh = ShadingMesh(verts, tris)
     quads = torch.from_numpy(scene.CROWN_LIGHT_QUADS.astype(np.float32)).to(dev)
     quad_n = torch.linalg.cross(quads[:, 1] - quads[:, 0], quads[:, 3] - quads[:, 0])
     quad_area = quad_n.norm(dim=1)
@@ -75,19 +76,17 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         hits = wf.IntersectClosest(n, rq, escaped=escaped, basic_eval_material=material)
+        intr = torch.empty((n, 40), dtype=torch.float32, device=dev)
+        smesh.interactions_device(hits.data_ptr(), n, intr.data_ptr(), ray_queue=rq,
+                                  stream=torch.cuda.current_stream(dev).cuda_stream)
         torch.cuda.synchronize()
         t_trace += time.perf_counter() - t0
         # ---- material + light-sampling stage over the material queue (indices into rq) ----
         idx = material.indices().long()
-        h = hits[idx].view(torch.float32).view(-1, 8)
-        prim = hits[idx].view(torch.int32).view(-1, 8)[:, 0].long()
-        t_hit = h[:, 1]
-        o, d = rq.o[:, idx].T, rq.d[:, idx].T
-        p = o + t_hit[:, None] * d
-        v = d_verts[d_tris[prim]]
-        ng = torch.linalg.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
-        ng = ng / ng.norm(dim=1, keepdim=True).clamp_min(1e-30)
-        ng = torch.where((ng * d).sum(1, keepdim=True) > 0, -ng, ng)  # face the camera
+        rec = intr[idx]                                   # nnbvh_interaction records of the hits
+        p = 0.5 * (rec[:, 0:3] + rec[:, 3:6])             # Point3f(pi)
+        ng, wo = rec[:, 12:15], rec[:, 8:11]
+        ng = torch.where((ng * wo).sum(1, keepdim=True) < 0, -ng, ng)  # face the camera
         k = torch.randint(0, len(quads), (len(idx),), device=dev, generator=gen)
         u = torch.rand((len(idx), 2), device=dev, generator=gen)
         pl = quads[k, 0] + u[:, :1] * (quads[k, 1] - quads[k, 0]) + u[:, 1:] * (quads[k, 3] - quads[k, 0])

@@ -175,4 +175,36 @@ class HipBVHAggregate {
     nnbvh_scene *scene_ = nullptr;
 };
 
+// Triangle::InteractionFromIntersection (shapes.h:884-1010) for batches of hit records: the mesh
+// side of a pbrt scene (TriangleMesh arrays flattened over all meshes) + the post-pass.
+class HipShadingMesh {
+  public:
+    HipShadingMesh(const float *verts, int nVerts, const int32_t *triVertices, int nTris,
+                   const float *normals = nullptr, const float *uvs = nullptr,
+                   const float *tangents = nullptr, const int32_t *faceIndices = nullptr,
+                   const uint8_t *triFlags = nullptr, int device = 0)
+        : mesh_(nnbvh_shading_mesh_create(verts, nVerts, triVertices, nTris, normals, uvs, tangents,
+                                          faceIndices, triFlags, device)) {
+        if (!mesh_) HipBVHAggregate::fatal("HipShadingMesh");
+    }
+    ~HipShadingMesh() { nnbvh_shading_mesh_destroy(mesh_); }
+    HipShadingMesh(const HipShadingMesh &) = delete;
+    HipShadingMesh &operator=(const HipShadingMesh &) = delete;
+
+    void Interactions(const nnbvh_ray *rays, const nnbvh_hit *hits, int32_t n, nnbvh_interaction *out) const {
+        if (nnbvh_triangle_interactions(mesh_, rays, hits, n, out) != NNBVH_OK)
+            HipBVHAggregate::fatal("Interactions");
+    }
+    // rays either as records (dRays) or as the wavefront SOA queue (raySoa); stream-ordered
+    void InteractionsDevice(const void *dRays, const nnbvh_ray_soa *raySoa, const void *dHits,
+                            int32_t maxItems, const int32_t *dSize, void *dOut, void *stream) const {
+        if (nnbvh_triangle_interactions_device(mesh_, dRays, raySoa, dHits, maxItems, dSize, dOut,
+                                               stream) != NNBVH_OK)
+            HipBVHAggregate::fatal("InteractionsDevice");
+    }
+
+  private:
+    nnbvh_shading_mesh *mesh_ = nullptr;
+};
+
 }  // namespace nnbvh

@@ -52,6 +52,26 @@ int main() {
         if (p != (occ[i] != 0) || p != si.has_value()) return 3;
         nHit += si.has_value();
     }
+    // hit records -> SurfaceInteraction (Triangle::InteractionFromIntersection)
+    std::vector<int32_t> triVerts;
+    for (int i = 0; i < nTris; ++i)
+        for (int k = 0; k < 3; ++k) triVerts.push_back(3 * i + k);
+    nnbvh::HipShadingMesh mesh(verts.data(), (int)verts.size() / 3, triVerts.data(), nTris);
+    std::vector<nnbvh_interaction> intr(nRays);
+    mesh.Interactions(rays.data(), hits.data(), nRays, intr.data());
+    for (int i = 0; i < nRays; ++i) {
+        if (intr[i].prim != hits[i].prim) return 5;
+        if ((hits[i].prim >= 0) != (intr[i].status == NNBVH_INTERACTION_TRIANGLE)) return 6;
+        if (hits[i].prim < 0) continue;
+        // the hit point lies on the ray at tHit, inside pi, and n is a unit vector
+        for (int a = 0; a < 3; ++a) {
+            float p = rays[i].o[a] + hits[i].t * rays[i].d[a];
+            float mid = 0.5f * (intr[i].pi_lo[a] + intr[i].pi_hi[a]);
+            if (std::fabs(p - mid) > 1e-3f * (1 + std::fabs(p))) return 7;
+        }
+        float n2 = intr[i].n[0] * intr[i].n[0] + intr[i].n[1] * intr[i].n[1] + intr[i].n[2] * intr[i].n[2];
+        if (std::fabs(n2 - 1) > 1e-5f) return 8;
+    }
     std::printf("adapter ok: %d rays, %d hits\n", nRays, nHit);
     return nHit > 0 ? 0 : 4;
 }
