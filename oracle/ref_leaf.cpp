@@ -15,16 +15,20 @@
 //   pbrt::Transform::ApplyInverse(Ray, Float *tMax)   (src/pbrt/util/transform.h:416-429, inline:
 //                                     the interval-arithmetic ray transform TransformedPrimitive
 //                                     applies, src/pbrt/cpu/primitive.cpp:112-131)
-// usage: ref_leaf <tri|blp|slab|xfray> <in.bin> <out.bin>
+//   pbrt::Transform::operator()(const Bounds3f &)     (src/pbrt/util/transform.cpp:134-139: the
+//                                     bounds TransformedPrimitive::Bounds() reports, cpu/primitive.h:91)
+// usage: ref_leaf <tri|blp|slab|xfray|xfbounds> <in.bin> <out.bin>
 //   in.bin : int32 n, then n records of float32
 //              tri : o[3] d[3] tmax p0[3] p1[3] p2[3]              (16 floats)
 //              blp : o[3] d[3] tmax p00[3] p10[3] p01[3] p11[3]    (19 floats)
 //              slab: o[3] d[3] tmax pmin[3] pmax[3]                (13 floats)
 //              xfray: o[3] d[3] tmax m[16] mInv[16] (row-major)     (39 floats)
+//              xfbounds: m[16] (row-major) pmin[3] pmax[3]          (22 floats)
 //   out.bin: n records: tri  -> int32 hit, float b0 b1 b2 t
 //                       blp  -> int32 hit, float u v t
 //                       slab -> int32 hit
 //                       xfray-> int32 1, float o'[3] d'[3] tmax'
+//                       xfbounds-> int32 1, float pmin'[3] pmax'[3]
 #include <pbrt/pbrt.h>
 #include <pbrt/ray.h>
 #include <pbrt/shapes.h>
@@ -46,8 +50,8 @@ int main(int argc, char **argv) {
         return 2;
     }
     int mode = !std::strcmp(argv[1], "tri") ? 0 : !std::strcmp(argv[1], "blp") ? 1
-               : !std::strcmp(argv[1], "slab") ? 2 : 3;
-    const int stride[4] = {16, 19, 13, 39};
+               : !std::strcmp(argv[1], "slab") ? 2 : !std::strcmp(argv[1], "xfray") ? 3 : 4;
+    const int stride[5] = {16, 19, 13, 39, 22};
     FILE *fi = std::fopen(argv[2], "rb");
     FILE *fo = std::fopen(argv[3], "wb");
     if (!fi || !fo) return 3;
@@ -91,6 +95,19 @@ int main(int argc, char **argv) {
             out[0] = tr.o.x, out[1] = tr.o.y, out[2] = tr.o.z;
             out[3] = tr.d.x, out[4] = tr.d.y, out[5] = tr.d.z;
             out[6] = t;
+        } else if (mode == 4) {
+            SquareMatrix<4> m;
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) m[a][b] = r[4 * a + b];
+            Transform xf(m);
+            Bounds3f b;
+            b.pMin = P(r + 16);
+            b.pMax = P(r + 19);
+            Bounds3f bt = xf(b);
+            hit = 1;
+            nout = 6;
+            out[0] = bt.pMin.x, out[1] = bt.pMin.y, out[2] = bt.pMin.z;
+            out[3] = bt.pMax.x, out[4] = bt.pMax.y, out[5] = bt.pMax.z;
         } else {
             Bounds3f b;
             b.pMin = P(r + 7);

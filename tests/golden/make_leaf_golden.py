@@ -220,13 +220,26 @@ def xfray_cases(rng):
     return np.concatenate([o, d, tmax[:, None], M.reshape(n, 16), Mi.reshape(n, 16)], 1).astype(np.float32)
 
 
+def xfbounds_cases(rng):
+    """Transform::operator()(Bounds3f) inputs: m[16] pmin[3] pmax[3] — the instance transforms of
+    xfray_cases applied to boxes of very different extents, incl. flat and point-like ones."""
+    n = 2048
+    m = xfray_cases(rng)[:n, 7:23]
+    lo = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-2, 3, size=(n, 1))
+    ext = 10.0 ** rng.uniform(-3, 3, size=(n, 3))
+    kind = rng.integers(0, 6, n)
+    ext[kind == 0, rng.integers(0, 3)] = 0.0  # flat box
+    ext[kind == 1] = 0.0                      # a point
+    return np.concatenate([m, lo, lo + ext], 1).astype(np.float32)
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/ref_leaf missing: run `make -C oracle ref` in the build container")
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20241008)
     for mode, gen, nout in (("tri", tri_cases, 4), ("blp", blp_cases, 3), ("slab", slab_cases, 0),
-                            ("xfray", xfray_cases, 7)):
+                            ("xfray", xfray_cases, 7), ("xfbounds", xfbounds_cases, 6)):
         recs = gen(rng)
         hit, bits = run_ref(mode, recs, nout)
         np.savez_compressed(os.path.join(OUT, f"leaf_{mode}.npz"), inputs=recs, hit=hit,

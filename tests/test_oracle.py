@@ -35,6 +35,20 @@ def test_ray_inverse_transform_matches_reference_vectors_bit_exact():
     assert (out[:, 6] != r[:, 6]).mean() > 0.2
 
 
+def test_transform_bounds_match_reference_vectors_bit_exact():
+    """Transform::operator()(Bounds3f) (util/transform.cpp:134-139) = TransformedPrimitive::Bounds():
+    the oracle's restatement AND the product's host function (nnbvh_transform_bounds, used when a
+    two-level scene is assembled) against vectors from the reference binary."""
+    from nn_bvh_amd.instancing import transform_bounds
+    g = np.load(os.path.join(GOLD, "leaf_xfbounds.npz"))
+    r = g["inputs"]
+    for i in range(len(r)):
+        exp = g["out_bits"][i]
+        assert (ob.transform_bounds(r[i, 0:12], r[i, 16:22]).view(np.uint32) == exp).all(), i
+        got = np.asarray(transform_bounds(r[i, 0:12], r[i, 16:22]), np.float32)
+        assert (got.view(np.uint32) == exp).all(), i
+
+
 def test_golden_vectors_reach_the_rare_branches():
     """The vectors must include exact-zero edge functions (the fp64 fallback), degenerate
     triangles and zero direction components, or the pin would not cover those branches."""
