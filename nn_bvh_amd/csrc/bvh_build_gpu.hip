@@ -280,6 +280,8 @@ __global__ __launch_bounds__(kB) void k_classify(int m, int maxPrims, const int 
 }
 
 // ---- 7: bounds ---------------------------------------------------------------------------------------
+constexpr int kBigLeaf = 64;  // leaves above this size are folded by a whole wavefront
+
 __global__ __launch_bounds__(kB) void k_leaf_bounds(int m, const unsigned char *__restrict__ kind,
                                                     const int *__restrict__ pstart,
                                                     const int *__restrict__ firstA,
@@ -292,10 +294,47 @@ __global__ __launch_bounds__(kB) void k_leaf_bounds(int m, const unsigned char *
     const bool internal = v < m - 1;
     const int first = internal ? firstA[v] : v - (m - 1);
     const int last = internal ? lastA[v] : first;
+    const int begin = pstart[first], end = pstart[last + 1];
+    if (end - begin > kBigLeaf) return;  // k_big_leaf_bounds
     Box6 b;
     box_init(b);
-    for (int j = pstart[first]; j < pstart[last + 1]; ++j) box_add(b, pb[idxSorted[j]]);  // :456-463
+    for (int j = begin; j < end; ++j) box_add(b, pb[idxSorted[j]]);  // :456-463
     nodeBox[v] = b;
+}
+
+// One wavefront per large leaf (runs of identical Morton codes can hold thousands of primitives).
+// The result must equal the sequential fold's, which keeps the FIRST of equal values (+0 / -0):
+// lanes fold contiguous chunks in order, and the cross-lane reduction always combines
+// (lower lane = earlier elements) on the left.
+__global__ __launch_bounds__(kB) void k_big_leaf_bounds(int m, const unsigned char *__restrict__ kind,
+                                                        const int *__restrict__ pstart,
+                                                        const int *__restrict__ firstA,
+                                                        const int *__restrict__ lastA,
+                                                        const int *__restrict__ idxSorted,
+                                                        const Box6 *__restrict__ pb,
+                                                        Box6 *__restrict__ nodeBox) {
+    const int v = blockIdx.x * (kB / 64) + (threadIdx.x >> 6);  // wave-uniform
+    if (v >= 2 * m - 1 || !(kind[v] & kRealLeaf)) return;
+    const bool internal = v < m - 1;
+    const int first = internal ? firstA[v] : v - (m - 1);
+    const int last = internal ? lastA[v] : first;
+    const int begin = pstart[first], n = pstart[last + 1] - begin;
+    if (n <= kBigLeaf) return;
+    const int lane = threadIdx.x & 63;
+    const int chunk = (n + 63) / 64;
+    const int lo = lane * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    Box6 b;
+    box_init(b);
+    for (int j = lo; j < hi; ++j) box_add(b, pb[idxSorted[begin + j]]);
+    for (int off = 1; off < 64; off <<= 1) {
+        Box6 o;
+        for (int k = 0; k < 3; ++k) {
+            o.mn[k] = __shfl_down(b.mn[k], off);
+            o.mx[k] = __shfl_down(b.mx[k], off);
+        }
+        if (lane + off < 64) box_add(b, o);  // b = earlier elements (kept on ties), o = later ones
+    }
+    if (lane == 0) nodeBox[v] = b;
 }
 
 __global__ __launch_bounds__(kB) void k_interior_bounds(int m, int level,
@@ -531,6 +570,8 @@ bool gpu_hlbvh(const nnbvh_prim *prims, int n, const float *verts, int n_verts,
              "scan treelets");
     hipLaunchKernelGGL(k_leaf_bounds, dim3(grid_all(nv)), dim3(kB), 0, stream, m, dKind, dPstart, dFirst, dLast, dIdxS,
                        dPb, dNodeBox);
+    hipLaunchKernelGGL(k_big_leaf_bounds, dim3((nv + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, stream, m, dKind, dPstart,
+                       dFirst, dLast, dIdxS, dPb, dNodeBox);
     if (m > 1)
         for (int level = 0; level < kTreeletBit; ++level)
             hipLaunchKernelGGL(k_interior_bounds, dim3(grid_all(m - 1)), dim3(kB), 0, stream, m, level, dKind, dBit,

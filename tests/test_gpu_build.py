@@ -53,6 +53,31 @@ def test_connected_mesh_and_duplicate_codes():
     del rng
 
 
+def test_signed_zeros_in_a_large_leaf_fold_like_the_sequential_builder():
+    """700 triangles with one centroid (one Morton code, one leaf) whose bounds mix +0 and -0: the
+    sequential fold keeps the first of equal values, and so must the wavefront-wide reduction."""
+    rng = np.random.default_rng(12)
+    n = 700
+    z = np.where(rng.random((n, 3)) < 0.5, 0.0, -0.0).astype(np.float32)
+    v = np.zeros((n, 3, 3), np.float32)
+    v[:, 0] = z                     # the minimum corner: +-0 per axis
+    v[:, 1] = [1, 1, 0]
+    v[:, 2] = [1, 0, 1]
+    v[:, 1, 2] = z[:, 2]
+    v[:, 2, 1] = z[:, 1]
+    verts = v.reshape(-1, 3)
+    prims = make_prims(np.arange(3 * n, dtype=np.int32).reshape(n, 3))
+    host = same_tree(prims, verts, what="signed zeros")
+    assert len(host.nodes) == 1 and host.nodes["nprims"][0] == n
+    assert np.signbit(verts[:, 0]).any() and not np.signbit(verts[:, 0]).all()
+    # ... and next to ordinary geometry, so that the leaf hangs inside a treelet
+    v2, p2 = ss.random_soup(4000, 0, 13)
+    p2 = p2.copy()
+    p2["v"][:, :3] += len(verts)
+    p2["id"] += n
+    same_tree(np.concatenate([prims, p2]), np.concatenate([verts, v2]), what="signed zeros + soup")
+
+
 def test_tiny_inputs():
     for n in (1, 2, 3, 5):
         verts, prims = ss.random_soup(n, 0, 20 + n)
