@@ -124,17 +124,22 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
                                             const float *verts, int n_verts,
                                             const float *prim_bounds, int max_prims_in_node,
                                             int split_method);
-/* HLBVH construction on the GPU (`device`): Morton codes, radix sort, the treelets' radix trees,
- * bounds and the DFS layout are computed on the device, only buildUpperSAH over the <= 4096
- * treelet roots (aggregates.cpp:626-723) runs on the host.  The result is byte-identical to
- * nnbvh_build_create_with_bounds(..., NNBVH_SPLIT_HLBVH) — the reference's buildHLBVH
- * (aggregates.cpp:389-503) with treelets emitted in Morton order.  NULL + nnbvh_last_error() on
- * failure (no device, allocation, malformed input). */
+/* Tree construction on the GPU (`device`), split_method NNBVH_SPLIT_SAH or NNBVH_SPLIT_HLBVH; the
+ * result (nodes, leaf-ordered primitives, depth) is byte-identical to
+ * nnbvh_build_create_with_bounds(..., split_method), i.e. to the reference's tree.
+ *   SAH   (buildRecursive, aggregates.cpp:192-387): nodes above 1024 primitives breadth-first with
+ *         whole-grid kernels, every smaller subtree by one wavefront; std::partition's exact
+ *         element order is reproduced from ballots / prefix sums.
+ *   HLBVH (buildHLBVH, aggregates.cpp:389-503 with treelets emitted in Morton order): Morton codes,
+ *         radix sort, the treelets' radix trees, bounds and the DFS layout on the device, only
+ *         buildUpperSAH over the <= 4096 treelet roots (aggregates.cpp:626-723) on the host.
+ * NULL + nnbvh_last_error() on failure (no device, allocation, malformed input). */
 nnbvh_build *nnbvh_build_create_gpu(const nnbvh_prim *prims, int n_prims, const float *verts,
                                     int n_verts, const float *prim_bounds, int max_prims_in_node,
-                                    int device);
-/* milliseconds of the last GPU build's phases: upload, device sort + tree, host upper SAH, device
- * emit, download (all zero for host builds) */
+                                    int split_method, int device);
+/* milliseconds of the last GPU build's phases (all zero for host builds) — HLBVH: upload, device
+ * sort + tree, host upper SAH, device emit, download; SAH: upload, big nodes breadth-first,
+ * wavefront subtrees, layout + bounds, download */
 int nnbvh_build_gpu_timing(const nnbvh_build *b, double out_ms[5]);
 const nnbvh_linear_node *nnbvh_build_nodes(const nnbvh_build *b, int *n_nodes);
 const nnbvh_prim *nnbvh_build_ordered_prims(const nnbvh_build *b, int *n_prims);

@@ -115,7 +115,7 @@ def lib():
     L.nnbvh_trace_batches_device.restype = i32
     L.nnbvh_trace_batches_device.argtypes = [vp, vp, i32, vp]
     L.nnbvh_build_create_gpu.restype = vp
-    L.nnbvh_build_create_gpu.argtypes = [vp, i32, vp, i32, vp, i32, i32]
+    L.nnbvh_build_create_gpu.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32]
     L.nnbvh_build_gpu_timing.restype = i32
     L.nnbvh_build_gpu_timing.argtypes = [vp, vp]
     L.nnbvh_shading_mesh_create.restype = vp

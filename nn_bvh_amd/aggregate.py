@@ -64,8 +64,7 @@ def _take_build(L, h, what):
         tree = BuiltTree(nodes, ordered, L.nnbvh_build_depth(h))
         ms = np.zeros(5, np.float64)
         L.nnbvh_build_gpu_timing(h, ptr(ms))
-        tree.gpu_ms = dict(zip(("upload", "device_tree", "host_upper_sah", "device_emit", "download"),
-                               (float(x) for x in ms)))
+        tree.gpu_ms = [float(x) for x in ms]  # phases: see nnbvh_build_gpu_timing
     finally:
         L.nnbvh_build_destroy(h)
     return tree
@@ -91,8 +90,10 @@ def build_tree(prims, verts, max_prims_in_node=4, split_method="sah", prim_bound
     return _take_build(L, h, "nnbvh_build_create")
 
 
-def build_tree_gpu(prims, verts, max_prims_in_node=4, prim_bounds=None, device=0):
-    """HLBVH built on the GPU: byte-identical to build_tree(..., split_method="hlbvh")."""
+def build_tree_gpu(prims, verts, max_prims_in_node=4, prim_bounds=None, device=0, split_method="hlbvh"):
+    """SAH or HLBVH tree built on the GPU: byte-identical to build_tree(..., split_method)."""
+    if split_method not in ("sah", "hlbvh"):
+        raise NNBVHError(f'GPU build supports "sah" and "hlbvh", not "{split_method}"')
     L = _lib.lib()
     prims = np.ascontiguousarray(prims, PRIM_DTYPE)
     verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
@@ -101,7 +102,7 @@ def build_tree_gpu(prims, verts, max_prims_in_node=4, prim_bounds=None, device=0
         pb = np.ascontiguousarray(prim_bounds, np.float32).reshape(len(prims), 6)
     h = L.nnbvh_build_create_gpu(ptr(prims), len(prims), ptr(verts), len(verts),
                                  ptr(pb) if pb is not None else None, int(max_prims_in_node),
-                                 int(device))
+                                 SPLIT_METHODS[split_method], int(device))
     return _take_build(L, h, "nnbvh_build_create_gpu")
 
 

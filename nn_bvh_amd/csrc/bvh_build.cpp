@@ -606,14 +606,21 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
 
 nnbvh_build *nnbvh_build_create_gpu(const nnbvh_prim *prims, int n_prims, const float *verts,
                                     int n_verts, const float *prim_bounds, int max_prims_in_node,
-                                    int device) {
+                                    int split_method, int device) {
     if (!prims || !verts || n_prims <= 0 || n_verts <= 0) {
         nnbvh::set_error("nnbvh_build_create_gpu: empty primitive or vertex array");
         return nullptr;
     }
+    if (split_method != NNBVH_SPLIT_SAH && split_method != NNBVH_SPLIT_HLBVH) {
+        nnbvh::set_error("nnbvh_build_create_gpu: only the sah and hlbvh split methods are built on the device");
+        return nullptr;
+    }
     nnbvh::GpuBuildResult r;
     std::string err;
-    if (!nnbvh::gpu_hlbvh(prims, n_prims, verts, n_verts, prim_bounds, max_prims_in_node, device, &r, &err)) {
+    const bool ok = split_method == NNBVH_SPLIT_SAH
+                        ? nnbvh::gpu_sah(prims, n_prims, verts, n_verts, prim_bounds, max_prims_in_node, device, &r, &err)
+                        : nnbvh::gpu_hlbvh(prims, n_prims, verts, n_verts, prim_bounds, max_prims_in_node, device, &r, &err);
+    if (!ok) {
         nnbvh::set_error(err);
         return nullptr;
     }
@@ -625,8 +632,11 @@ nnbvh_build *nnbvh_build_create_gpu(const nnbvh_prim *prims, int n_prims, const 
     out->n_treelets = r.n_treelets;
     out->n_unique_codes = r.n_unique_codes;
     if (std::getenv("NNBVH_BUILD_TIMING"))
-        std::fprintf(stderr, "nnbvh_build (gpu hlbvh): upload %.1f ms, device sort+tree %.1f ms, upper SAH (host) "
-                             "%.1f ms, emit %.1f ms, download %.1f ms; %d distinct codes, %d treelets\n",
+        std::fprintf(stderr, split_method == NNBVH_SPLIT_SAH
+                                 ? "nnbvh_build (gpu sah): upload %.1f ms, big nodes %.1f ms, subtrees %.1f ms, layout+bounds "
+                                   "%.1f ms, download %.1f ms; %d breadth-first nodes, %d subtrees\n"
+                                 : "nnbvh_build (gpu hlbvh): upload %.1f ms, device sort+tree %.1f ms, upper SAH (host) "
+                                   "%.1f ms, emit %.1f ms, download %.1f ms; %d distinct codes, %d treelets\n",
                      r.ms[0], r.ms[1], r.ms[2], r.ms[3], r.ms[4], r.n_unique_codes, r.n_treelets);
     return out;
 }

@@ -38,4 +38,10 @@ bool gpu_hlbvh(const nnbvh_prim *prims, int n_prims, const float *verts, int n_v
                const float *prim_bounds, int max_prims_in_node, int device, GpuBuildResult *out,
                std::string *error);
 
+// SAH (buildRecursive's default branch) on the device; same tree and leaf order as the host builder.
+// ms: upload, big nodes breadth-first, subtrees (one wavefront each), layout + bounds, download;
+// n_treelets = subtrees built by wavefronts, n_unique_codes = nodes built breadth-first.
+bool gpu_sah(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts, const float *prim_bounds,
+             int max_prims_in_node, int device, GpuBuildResult *out, std::string *error);
+
 }  // namespace nnbvh

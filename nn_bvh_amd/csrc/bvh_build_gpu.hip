@@ -644,4 +644,800 @@ bool gpu_hlbvh(const nnbvh_prim *prims, int n, const float *verts, int n_verts,
     return true;
 }
 
+
+// =================================================================================================
+// SAH build on the device: buildRecursive's SAH branch (aggregates.cpp:192-387) with the SAME tree
+// and the SAME leaf-ordered primitive table as the host builder (bvh_build.cpp), hence as the
+// reference.  What makes that possible:
+//   * every split decision depends only on the SET of primitives of a node (bounds, centroid bounds,
+//     12 bucket counts / bounds: exact min / max / integer sums, order-free) and on float
+//     expressions evaluated here operation for operation (sah_choose below is compiled for host
+//     and device from one source, -ffp-contract=off);
+//   * the ORDER of primitives — which decides the leaf table and every later std::nth_element tie —
+//     is what std::partition leaves behind, and libstdc++'s partition has a closed form: elements
+//     of the left part that satisfy the predicate and elements of the right part that do not stay
+//     where they are; the k-th offender of the left part (from the left) is swapped with the k-th
+//     offender of the right part counted from the RIGHT end.  Ranks come from ballots / prefix sums,
+//     so a node is partitioned in parallel with the sequential algorithm's exact result;
+//   * stored bounds: a leaf's are the in-order fold over its primitives, an interior node's the
+//     fold child 0 then child 1 (:371-373) — done after the layout, level by level from the leaves.
+// Phase A: nodes with more than kSmallSegment primitives, breadth-first, whole-grid kernels per
+//          level (tile = 2048 primitives of one node), the 12-bucket decision on the host (a few
+//          thousand nodes in total).
+// Phase B: every remaining subtree is built depth-first by ONE wavefront (explicit stack in LDS,
+//          nodes written in DFS order into the subtree's pool slice).
+// Phase C: DFS layout of the phase-A nodes + subtree slices, copy, bounds, download.
+namespace {
+
+constexpr int kSahBuckets = 12;
+constexpr int kSmallSegment = 1024;
+constexpr int kTile = 2048;
+
+struct HBox {
+    float mn[3], mx[3];
+};
+__host__ __device__ inline void hb_init(HBox &b) {
+    for (int k = 0; k < 3; ++k) {
+        b.mn[k] = 3.402823466e+38f;
+        b.mx[k] = -3.402823466e+38f;
+    }
+}
+__host__ __device__ inline void hb_add(HBox &b, const HBox &o) {  // Union, first of equals kept
+    for (int k = 0; k < 3; ++k) {
+        b.mn[k] = o.mn[k] < b.mn[k] ? o.mn[k] : b.mn[k];
+        b.mx[k] = b.mx[k] < o.mx[k] ? o.mx[k] : b.mx[k];
+    }
+}
+__host__ __device__ inline float hb_area(const HBox &b) {  // util/vecmath.h:1293-1296
+    const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    return 2 * (dx * dy + dx * dz + dy * dz);
+}
+__host__ __device__ inline int hb_maxdim(const HBox &b) {  // util/vecmath.h:1305-1313
+    const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    if (dx > dy && dx > dz) return 0;
+    else if (dy > dz) return 1;
+    else return 2;
+}
+// which of the 12 buckets a primitive's centroid falls in (:312-317, Bounds3::Offset vecmath.h:1322-1331)
+__host__ __device__ inline int sah_bucket(float centroid, float cmn, float cmx) {
+    float o = centroid - cmn;
+    if (cmx > cmn) o /= cmx - cmn;
+    int b = kSahBuckets * o;
+    if (b == kSahBuckets) b = kSahBuckets - 1;
+    return b;
+}
+// the decision of :319-371 from the node's buckets: best split, how many primitives go left,
+// and whether the node is split at all
+struct SahChoice {
+    int best, mid, split;
+};
+__host__ __device__ inline SahChoice sah_choose(const int *count, const HBox *bb, const HBox &bounds, int n,
+                                                int maxPrims) {
+    constexpr int nSplits = kSahBuckets - 1;
+    float costs[nSplits];
+    for (int i = 0; i < nSplits; ++i) costs[i] = 0;
+    int below = 0;
+    HBox bbelow;
+    hb_init(bbelow);
+    for (int i = 0; i < nSplits; ++i) {
+        hb_add(bbelow, bb[i]);
+        below += count[i];
+        costs[i] += below * hb_area(bbelow);
+    }
+    int above = 0;
+    HBox babove;
+    hb_init(babove);
+    for (int i = nSplits; i >= 1; --i) {
+        hb_add(babove, bb[i]);
+        above += count[i];
+        costs[i - 1] += above * hb_area(babove);
+    }
+    int best = -1;
+    float minCost = __builtin_inff();
+    for (int i = 0; i < nSplits; ++i)
+        if (costs[i] < minCost) {
+            minCost = costs[i];
+            best = i;
+        }
+    const float leafCost = (float)n;
+    minCost = 1.f / 2.f + minCost / hb_area(bounds);
+    SahChoice c;
+    c.best = best;
+    c.split = (n > maxPrims || minCost < leafCost) ? 1 : 0;
+    c.mid = 0;
+    for (int i = 0; i <= best; ++i) c.mid += count[i];
+    return c;
+}
+
+__device__ __forceinline__ float centroid_of(const Box6 &b, int dim) { return .5f * b.mn[dim] + .5f * b.mx[dim]; }
+
+// ---- phase A ---------------------------------------------------------------------------------------
+struct Tile {
+    int seg, start, n;  // a run of one big node's primitives
+};
+struct SegInfo {  // per big node of the current level
+    int start, n, mid, dim, best;
+    float cmn, cmx;  // centroid bounds in `dim`
+};
+
+// bounds and centroid bounds of every big node of the level (values; the sign of zeros is not needed)
+__global__ __launch_bounds__(kB) void k_seg_reduce(const Tile *__restrict__ tiles, const Box6 *__restrict__ pb,
+                                                   const int *__restrict__ perm, unsigned *segAcc) {
+    __shared__ float red[12][kB / 64];
+    const Tile t = tiles[blockIdx.x];
+    float v[12];
+    for (int k = 0; k < 3; ++k) {
+        v[k] = v[6 + k] = 3.402823466e+38f;
+        v[3 + k] = v[9 + k] = -3.402823466e+38f;
+    }
+    for (int j = threadIdx.x; j < t.n; j += kB) {
+        const Box6 b = pb[perm[t.start + j]];
+        for (int k = 0; k < 3; ++k) {
+            v[k] = fminf(v[k], b.mn[k]);
+            v[3 + k] = fmaxf(v[3 + k], b.mx[k]);
+            const float c = .5f * b.mn[k] + .5f * b.mx[k];
+            v[6 + k] = fminf(v[6 + k], c);
+            v[9 + k] = fmaxf(v[9 + k], c);
+        }
+    }
+    for (int q = 0; q < 12; ++q) {
+        const bool isMin = (q % 6) < 3;
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float o = __shfl_xor(v[q], off);
+            v[q] = isMin ? fminf(v[q], o) : fmaxf(v[q], o);
+        }
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < 12; ++q) red[q][threadIdx.x >> 6] = v[q];
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const int q = threadIdx.x;
+        const bool isMin = (q % 6) < 3;
+        float r = red[q][0];
+        for (int w = 1; w < kB / 64; ++w) r = isMin ? fminf(r, red[q][w]) : fmaxf(r, red[q][w]);
+        if (isMin) atomicMin(&segAcc[12 * t.seg + q], f2key(r));
+        else atomicMax(&segAcc[12 * t.seg + q], f2key(r));
+    }
+}
+
+// the 12 buckets of every big node: counts and bounds (:305-318)
+__global__ __launch_bounds__(kB) void k_seg_buckets(const Tile *__restrict__ tiles, const SegInfo *__restrict__ info,
+                                                    const Box6 *__restrict__ pb, const int *__restrict__ perm,
+                                                    unsigned *segKeys, int *segCounts) {
+    __shared__ unsigned keys[kSahBuckets * 6];
+    __shared__ int counts[kSahBuckets];
+    const Tile t = tiles[blockIdx.x];
+    const SegInfo si = info[t.seg];
+    if (threadIdx.x < kSahBuckets) counts[threadIdx.x] = 0;
+    if (threadIdx.x < kSahBuckets * 6) keys[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u;
+    __syncthreads();
+    for (int j = threadIdx.x; j < t.n; j += kB) {
+        const Box6 b = pb[perm[t.start + j]];
+        const int bk = sah_bucket(centroid_of(b, si.dim), si.cmn, si.cmx);
+        atomicAdd(&counts[bk], 1);
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&keys[bk * 6 + k], f2key(b.mn[k]));
+            atomicMax(&keys[bk * 6 + 3 + k], f2key(b.mx[k]));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kSahBuckets && counts[threadIdx.x]) atomicAdd(&segCounts[kSahBuckets * t.seg + threadIdx.x], counts[threadIdx.x]);
+    if (threadIdx.x < kSahBuckets * 6 && counts[threadIdx.x / 6]) {
+        if ((threadIdx.x % 6) < 3) atomicMin(&segKeys[kSahBuckets * 6 * t.seg + threadIdx.x], keys[threadIdx.x]);
+        else atomicMax(&segKeys[kSahBuckets * 6 * t.seg + threadIdx.x], keys[threadIdx.x]);
+    }
+}
+
+// std::partition, step 1: who is on the wrong side of `mid`
+__global__ __launch_bounds__(kB) void k_seg_flags(const Tile *__restrict__ tiles, const SegInfo *__restrict__ info,
+                                                  const Box6 *__restrict__ pb, const int *__restrict__ perm,
+                                                  int *__restrict__ lfFlag, int *__restrict__ rtFlag) {
+    const Tile t = tiles[blockIdx.x];
+    const SegInfo si = info[t.seg];
+    for (int j = threadIdx.x; j < t.n; j += kB) {
+        const int i = t.start + j;
+        const bool pred = sah_bucket(centroid_of(pb[perm[i]], si.dim), si.cmn, si.cmx) <= si.best;
+        const bool left = i < si.start + si.mid;
+        lfFlag[i] = (left && !pred) ? 1 : 0;
+        rtFlag[i] = (!left && pred) ? 1 : 0;
+    }
+}
+// step 2: the k-th offender of the left part (from the left) and of the right part (from the right)
+__global__ __launch_bounds__(kB) void k_seg_positions(const Tile *__restrict__ tiles, const SegInfo *__restrict__ info,
+                                                      const int *__restrict__ lfFlag, const int *__restrict__ lfScan,
+                                                      const int *__restrict__ rtFlag, const int *__restrict__ rtScan,
+                                                      int *__restrict__ lfPos, int *__restrict__ rtPos) {
+    const Tile t = tiles[blockIdx.x];
+    const SegInfo si = info[t.seg];
+    const int end = si.start + si.n;
+    for (int j = threadIdx.x; j < t.n; j += kB) {
+        const int i = t.start + j;
+        if (lfFlag[i]) lfPos[si.start + (lfScan[i] - lfScan[si.start])] = i;
+        if (rtFlag[i]) rtPos[si.start + (rtScan[end] - rtScan[i + 1])] = i;
+    }
+}
+// step 3: swap them pairwise
+__global__ __launch_bounds__(kB) void k_seg_swap(const Tile *__restrict__ tiles, const SegInfo *__restrict__ info,
+                                                 const int *__restrict__ lfScan, const int *__restrict__ lfPos,
+                                                 const int *__restrict__ rtPos, int *perm) {
+    const Tile t = tiles[blockIdx.x];
+    const SegInfo si = info[t.seg];
+    const int nSwaps = lfScan[si.start + si.mid] - lfScan[si.start];
+    for (int j = threadIdx.x; j < t.n; j += kB) {
+        const int k = t.start + j - si.start;
+        if (k < nSwaps) {
+            const int a = lfPos[si.start + k], b = rtPos[si.start + k];
+            const int va = perm[a], vb = perm[b];
+            perm[a] = vb;
+            perm[b] = va;
+        }
+    }
+}
+
+// ---- phase B: one wavefront builds one subtree ----------------------------------------------------------
+struct SmallSeg {
+    int start, n, pool;
+};
+constexpr int kSubtreeStack = 64;
+
+__global__ __launch_bounds__(64) void k_sah_subtrees(const SmallSeg *__restrict__ segs, int nSegs, int maxPrims,
+                                                     const Box6 *__restrict__ pb, int *perm, int *lfPos, int *rtPos,
+                                                     nnbvh_linear_node *pool, int *segCount, int *segDepth,
+                                                     int *err) {
+    __shared__ int stStart[kSubtreeStack], stN[kSubtreeStack], stParent[kSubtreeStack], stDepth[kSubtreeStack];
+    __shared__ unsigned bkeys[kSahBuckets * 6];
+    __shared__ int bcount[kSahBuckets];
+    const int s = blockIdx.x;
+    if (s >= nSegs) return;
+    const int lane = threadIdx.x;
+    const SmallSeg sg = segs[s];
+    nnbvh_linear_node *nodes = pool + sg.pool;
+    int sp = 0, idx = 0, maxDepth = 0;
+    int start = sg.start, n = sg.n, depth = 0;
+    for (;;) {
+        const int me = idx++;
+        // bounds and centroid bounds of the node (values)
+        float v[12];
+        for (int k = 0; k < 3; ++k) {
+            v[k] = v[6 + k] = 3.402823466e+38f;
+            v[3 + k] = v[9 + k] = -3.402823466e+38f;
+        }
+        for (int j = lane; j < n; j += 64) {
+            const Box6 b = pb[perm[start + j]];
+            for (int k = 0; k < 3; ++k) {
+                v[k] = fminf(v[k], b.mn[k]);
+                v[3 + k] = fmaxf(v[3 + k], b.mx[k]);
+                const float c = .5f * b.mn[k] + .5f * b.mx[k];
+                v[6 + k] = fminf(v[6 + k], c);
+                v[9 + k] = fmaxf(v[9 + k], c);
+            }
+        }
+        for (int q = 0; q < 12; ++q) {
+            const bool isMin = (q % 6) < 3;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float o = __shfl_xor(v[q], off);
+                v[q] = isMin ? fminf(v[q], o) : fmaxf(v[q], o);
+            }
+            v[q] = __shfl(v[q], 0);  // one value for the whole wavefront (a zero's sign may differ per lane)
+        }
+        HBox bounds, cb;
+        for (int k = 0; k < 3; ++k) {
+            bounds.mn[k] = v[k], bounds.mx[k] = v[3 + k];
+            cb.mn[k] = v[6 + k], cb.mx[k] = v[9 + k];
+        }
+        bool leaf = hb_area(bounds) == 0 || n == 1;  // :221
+        int dim = 0, mid = 0, best = 0;
+        if (!leaf) {
+            dim = hb_maxdim(cb);
+            if (cb.mx[dim] == cb.mn[dim]) leaf = true;  // :243
+        }
+        if (!leaf) {
+            if (n <= 2) {  // :289-296: nth_element of two = put the smaller centroid first
+                if (lane == 0) {
+                    const int i0 = perm[start], i1 = perm[start + 1];
+                    if (centroid_of(pb[i1], dim) < centroid_of(pb[i0], dim)) {
+                        perm[start] = i1;
+                        perm[start + 1] = i0;
+                    }
+                }
+                mid = n / 2;
+            } else {
+                if (lane < kSahBuckets) bcount[lane] = 0;
+                for (int q = lane; q < kSahBuckets * 6; q += 64) bkeys[q] = (q % 6) < 3 ? 0xffffffffu : 0u;
+                __syncthreads();
+                for (int j = lane; j < n; j += 64) {
+                    const Box6 b = pb[perm[start + j]];
+                    const int bk = sah_bucket(centroid_of(b, dim), cb.mn[dim], cb.mx[dim]);
+                    atomicAdd(&bcount[bk], 1);
+                    for (int k = 0; k < 3; ++k) {
+                        atomicMin(&bkeys[bk * 6 + k], f2key(b.mn[k]));
+                        atomicMax(&bkeys[bk * 6 + 3 + k], f2key(b.mx[k]));
+                    }
+                }
+                __syncthreads();
+                int count[kSahBuckets];
+                HBox bb[kSahBuckets];
+                for (int b = 0; b < kSahBuckets; ++b) {
+                    count[b] = bcount[b];
+                    for (int k = 0; k < 3; ++k) {
+                        bb[b].mn[k] = key2f(bkeys[b * 6 + k]);
+                        bb[b].mx[k] = key2f(bkeys[b * 6 + 3 + k]);
+                    }
+                }
+                const SahChoice ch = sah_choose(count, bb, bounds, n, maxPrims);
+                __syncthreads();  // everyone has read the buckets before the next node clears them
+                if (!ch.split) {
+                    leaf = true;
+                } else {
+                    best = ch.best;
+                    mid = ch.mid;
+                    // std::partition(bucket <= best) by ranks: offenders of the left part from the left ...
+                    int nl = 0;
+                    for (int base = 0; base < mid; base += 64) {
+                        const int j = base + lane;
+                        bool f = false;
+                        if (j < mid)
+                            f = sah_bucket(centroid_of(pb[perm[start + j]], dim), cb.mn[dim], cb.mx[dim]) > best;
+                        const unsigned long long mask = __ballot(f);
+                        if (f) lfPos[start + nl + __popcll(mask & ((1ull << lane) - 1ull))] = start + j;
+                        nl += __popcll(mask);
+                    }
+                    // ... offenders of the right part from the right
+                    int nr = 0;
+                    for (int top = n; top > mid; top -= 64) {
+                        const int j = top - 1 - lane;
+                        bool f = false;
+                        if (j >= mid)
+                            f = sah_bucket(centroid_of(pb[perm[start + j]], dim), cb.mn[dim], cb.mx[dim]) <= best;
+                        const unsigned long long mask = __ballot(f);
+                        if (f) rtPos[start + nr + __popcll(mask & ((1ull << lane) - 1ull))] = start + j;
+                        nr += __popcll(mask);
+                    }
+                    if (nl != nr && lane == 0) *err = 100;  // cannot happen: both equal the number of swaps
+                    __threadfence_block();
+                    for (int k = lane; k < nl; k += 64) {
+                        const int a = lfPos[start + k], b = rtPos[start + k];
+                        const int va = perm[a], vb = perm[b];
+                        perm[a] = vb;
+                        perm[b] = va;
+                    }
+                    __threadfence_block();
+                }
+            }
+        }
+        if (!leaf) {
+            if (mid <= 0 || mid >= n) {  // cannot happen (buckets 0 and 11 are never empty): no endless loop
+                if (lane == 0) *err = 101;
+                leaf = true;
+            }
+        }
+        if (!leaf) {
+            if (lane == 0) {
+                nnbvh_linear_node nd;
+                for (int k = 0; k < 3; ++k) nd.pmin[k] = nd.pmax[k] = 0;
+                nd.offset = 0;  // second child: set when it is created
+                nd.nprims = 0;
+                nd.axis = (uint8_t)dim;
+                nd.pad = (uint8_t)depth;  // carried to phase C, cleared there
+                nodes[me] = nd;
+            }
+            if (sp >= kSubtreeStack) {
+                if (lane == 0) *err = 102;
+                break;
+            }
+            if (lane == 0) {
+                stStart[sp] = start + mid;
+                stN[sp] = n - mid;
+                stParent[sp] = me;
+                stDepth[sp] = depth + 1;
+            }
+            ++sp;
+            n = mid;
+            ++depth;
+            __syncthreads();
+            continue;
+        }
+        // leaf (:222-236 / :243-253 / :365-369): bounds = in-order fold over its primitives
+        {
+            const int chunk = (n + 63) / 64;
+            const int lo = lane * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+            Box6 b;
+            box_init(b);
+            for (int j = lo; j < hi; ++j) box_add(b, pb[perm[start + j]]);
+            for (int off = 1; off < 64; off <<= 1) {
+                Box6 o;
+                for (int k = 0; k < 3; ++k) {
+                    o.mn[k] = __shfl_down(b.mn[k], off);
+                    o.mx[k] = __shfl_down(b.mx[k], off);
+                }
+                if (lane + off < 64) box_add(b, o);
+            }
+            if (lane == 0) {
+                nnbvh_linear_node nd;
+                for (int k = 0; k < 3; ++k) {
+                    nd.pmin[k] = b.mn[k];
+                    nd.pmax[k] = b.mx[k];
+                }
+                nd.offset = start;
+                nd.nprims = (uint16_t)n;
+                nd.axis = 0;
+                nd.pad = (uint8_t)depth;
+                nodes[me] = nd;
+                if (n > 65535) *err = kErrLeafSize;
+            }
+            if (depth > maxDepth) maxDepth = depth;
+        }
+        if (sp == 0) break;
+        --sp;
+        __syncthreads();
+        start = stStart[sp];
+        n = stN[sp];
+        depth = stDepth[sp];
+        if (lane == 0) nodes[stParent[sp]].offset = idx;  // the node about to be created
+        __syncthreads();
+    }
+    if (lane == 0) {
+        segCount[s] = idx;
+        segDepth[s] = maxDepth;
+    }
+}
+
+// ---- phase C ----------------------------------------------------------------------------------------------
+// subtree slices -> final DFS positions
+__global__ __launch_bounds__(kB) void k_sah_emit(const SmallSeg *__restrict__ segs, const int *__restrict__ segCount,
+                                                 const int *__restrict__ segBase, const int *__restrict__ segBaseDepth,
+                                                 const nnbvh_linear_node *__restrict__ pool,
+                                                 nnbvh_linear_node *__restrict__ nodes, unsigned char *__restrict__ depthOf) {
+    const int s = blockIdx.x;
+    const int cnt = segCount[s], base = segBase[s], bd = segBaseDepth[s];
+    const nnbvh_linear_node *src = pool + segs[s].pool;
+    for (int i = threadIdx.x; i < cnt; i += kB) {
+        nnbvh_linear_node nd = src[i];
+        depthOf[base + i] = (unsigned char)(bd + nd.pad);
+        nd.pad = 0;
+        if (nd.nprims == 0) nd.offset += base;
+        nodes[base + i] = nd;
+    }
+}
+struct UpperNode {
+    int index, second, axis, depth;
+};
+__global__ __launch_bounds__(kB) void k_sah_upper(const UpperNode *__restrict__ up, int nUp,
+                                                  nnbvh_linear_node *__restrict__ nodes, unsigned char *__restrict__ depthOf) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= nUp) return;
+    nnbvh_linear_node nd;
+    for (int k = 0; k < 3; ++k) nd.pmin[k] = nd.pmax[k] = 0;
+    nd.offset = up[i].second;
+    nd.nprims = 0;
+    nd.axis = (uint8_t)up[i].axis;
+    nd.pad = 0;
+    nodes[up[i].index] = nd;
+    depthOf[up[i].index] = (unsigned char)up[i].depth;
+}
+// interior bounds = Union(child 0, child 1) (:371-373), one tree level per launch, deepest first
+__global__ __launch_bounds__(kB) void k_sah_level_bounds(int nNodes, int level, const unsigned char *__restrict__ depthOf,
+                                                         nnbvh_linear_node *nodes) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= nNodes || depthOf[i] != level || nodes[i].nprims != 0) return;
+    const nnbvh_linear_node c0 = nodes[i + 1], c1 = nodes[nodes[i].offset];
+    Box6 b, o;
+    box_init(b);
+    for (int k = 0; k < 3; ++k) o.mn[k] = c0.pmin[k], o.mx[k] = c0.pmax[k];
+    box_add(b, o);
+    for (int k = 0; k < 3; ++k) o.mn[k] = c1.pmin[k], o.mx[k] = c1.pmax[k];
+    box_add(b, o);
+    for (int k = 0; k < 3; ++k) nodes[i].pmin[k] = b.mn[k], nodes[i].pmax[k] = b.mx[k];
+}
+
+struct HostNode {  // a phase-A node
+    int child[2];  // >= 0: HostNode index; < 0: ~(small segment index)
+    int axis;
+};
+
+}  // namespace
+
+bool gpu_sah(const nnbvh_prim *prims, int n, const float *verts, int n_verts, const float *prim_bounds,
+             int max_prims_in_node, int device, GpuBuildResult *out, std::string *error) {
+    int prev = 0;
+    GB_CHECK(hipGetDevice(&prev), "hipGetDevice");
+    GB_CHECK(hipSetDevice(device), "hipSetDevice");
+    struct Restore {
+        int d;
+        ~Restore() { (void)hipSetDevice(d); }
+    } restore{prev};
+    const int maxPrims = std::min(255, max_prims_in_node);
+    hipStream_t stream = nullptr;
+    DevMem mem;
+    mem.error = error;
+
+    auto t0 = std::chrono::steady_clock::now();
+    nnbvh_prim *dPrims = mem.get<nnbvh_prim>(n);
+    float *dVerts = mem.get<float>(3 * (size_t)n_verts);
+    float *dCaller = prim_bounds ? mem.get<float>(6 * (size_t)n) : nullptr;
+    Box6 *dPb = mem.get<Box6>(n);
+    int *dPerm = mem.get<int>(n);
+    int *dLfFlag = mem.get<int>((size_t)n + 1), *dRtFlag = mem.get<int>((size_t)n + 1);
+    int *dLfScan = mem.get<int>((size_t)n + 1), *dRtScan = mem.get<int>((size_t)n + 1);
+    int *dLfPos = mem.get<int>(n), *dRtPos = mem.get<int>(n);
+    unsigned *dCodesUnused = mem.get<unsigned>(n);
+    int *dScalars = mem.get<int>(16);
+    if (!mem.ok) return false;
+    GB_CHECK(hipMemcpyAsync(dPrims, prims, (size_t)n * sizeof(nnbvh_prim), hipMemcpyHostToDevice, stream), "copy prims");
+    GB_CHECK(hipMemcpyAsync(dVerts, verts, 3 * (size_t)n_verts * sizeof(float), hipMemcpyHostToDevice, stream), "copy verts");
+    if (dCaller)
+        GB_CHECK(hipMemcpyAsync(dCaller, prim_bounds, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream), "copy bounds");
+    const int init[16] = {-1, -1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    GB_CHECK(hipMemcpyAsync(dScalars, init, sizeof init, hipMemcpyHostToDevice, stream), "init scalars");
+    GB_CHECK(hipStreamSynchronize(stream), "sync after upload");
+    out->ms[0] = ms_since(t0);
+
+    t0 = std::chrono::steady_clock::now();
+    int *dErr = dScalars + 6;
+    hipLaunchKernelGGL(k_prim_bounds, dim3(grid_for(n, 1024)), dim3(kB), 0, stream, dPrims, dVerts, n_verts, dCaller, n,
+                       dPb, (unsigned *)dScalars, dErr);
+    hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kB), 0, stream, dPb, (unsigned *)dScalars, n, dCodesUnused,
+                       dPerm);  // only for perm[i] = i
+    size_t scanBytes = 0;
+    GB_CHECK(rocprim::exclusive_scan(nullptr, scanBytes, dLfFlag, dLfScan, 0, (size_t)n + 1, rocprim::plus<int>(), stream),
+             "scan (size query)");
+    void *dTmp = mem.get<char>(scanBytes);
+    if (!mem.ok) return false;
+    int errNow = 0;
+    GB_CHECK(hipMemcpyAsync(&errNow, dErr, sizeof(int), hipMemcpyDeviceToHost, stream), "read error flag");
+    GB_CHECK(hipStreamSynchronize(stream), "sync after bounds");
+    if (errNow != 0) {
+        *error = errNow == kErrVertex       ? "nnbvh_build_create: vertex index out of range"
+                 : errNow == kErrNeedBounds ? "nnbvh_build_create: instance / host primitives need prim_bounds"
+                                            : "nnbvh_build_create: unknown primitive kind";
+        return false;
+    }
+
+    // ---- phase A: big nodes, breadth-first -------------------------------------------------------------
+    struct Big {
+        int start, n, host;  // host = HostNode index
+    };
+    std::vector<HostNode> hostNodes;
+    std::vector<SmallSeg> smallSegs;
+    std::vector<Big> level;
+    int rootRef;  // >= 0 host node, < 0 ~small segment
+    auto make_child = [&](int start, int cnt, std::vector<Big> &next) -> int {
+        if (cnt > kSmallSegment) {
+            hostNodes.push_back(HostNode{{0, 0}, 0});
+            next.push_back(Big{start, cnt, (int)hostNodes.size() - 1});
+            return (int)hostNodes.size() - 1;
+        }
+        smallSegs.push_back(SmallSeg{start, cnt, 0});
+        return ~((int)smallSegs.size() - 1);
+    };
+    rootRef = make_child(0, n, level);
+    std::vector<Tile> tiles;
+    std::vector<SegInfo> infos;
+    std::vector<unsigned> acc, bkeys;
+    std::vector<int> bcounts;
+    Tile *dTiles = nullptr;
+    SegInfo *dInfo = nullptr;
+    unsigned *dAcc = nullptr, *dBKeys = nullptr;
+    int *dBCounts = nullptr;
+    size_t capTiles = 0, capSegs = 0;
+    while (!level.empty()) {
+        const int nSeg = (int)level.size();
+        tiles.clear();
+        for (int s = 0; s < nSeg; ++s)
+            for (int off = 0; off < level[s].n; off += kTile)
+                tiles.push_back(Tile{s, level[s].start + off, std::min(kTile, level[s].n - off)});
+        if (tiles.size() > capTiles) {
+            capTiles = tiles.size() * 2;
+            dTiles = mem.get<Tile>(capTiles);
+        }
+        if ((size_t)nSeg > capSegs) {
+            capSegs = (size_t)nSeg * 2;
+            dInfo = mem.get<SegInfo>(capSegs);
+            dAcc = mem.get<unsigned>(12 * capSegs);
+            dBKeys = mem.get<unsigned>(kSahBuckets * 6 * capSegs);
+            dBCounts = mem.get<int>(kSahBuckets * capSegs);
+        }
+        if (!mem.ok) return false;
+        const int nTiles = (int)tiles.size();
+        GB_CHECK(hipMemcpyAsync(dTiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, stream), "copy tiles");
+        acc.assign(12 * (size_t)nSeg, 0u);
+        for (int s = 0; s < nSeg; ++s)
+            for (int q = 0; q < 12; ++q) acc[12 * (size_t)s + q] = (q % 6) < 3 ? 0xffffffffu : 0u;
+        GB_CHECK(hipMemcpyAsync(dAcc, acc.data(), acc.size() * sizeof(unsigned), hipMemcpyHostToDevice, stream), "init accumulators");
+        hipLaunchKernelGGL(k_seg_reduce, dim3(nTiles), dim3(kB), 0, stream, dTiles, dPb, dPerm, dAcc);
+        GB_CHECK(hipMemcpyAsync(acc.data(), dAcc, acc.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream), "read accumulators");
+        GB_CHECK(hipStreamSynchronize(stream), "sync (bounds)");
+        auto key_to_float = [](unsigned k) {
+            const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+            float f;
+            std::memcpy(&f, &u, 4);
+            return f;
+        };
+        infos.assign((size_t)nSeg, SegInfo{});
+        std::vector<HBox> segBounds((size_t)nSeg);
+        std::vector<char> delegate((size_t)nSeg, 0);  // the wavefront builder will make the leaf
+        for (int s = 0; s < nSeg; ++s) {
+            HBox b, cb;
+            for (int k = 0; k < 3; ++k) {
+                b.mn[k] = key_to_float(acc[12 * (size_t)s + k]);
+                b.mx[k] = key_to_float(acc[12 * (size_t)s + 3 + k]);
+                cb.mn[k] = key_to_float(acc[12 * (size_t)s + 6 + k]);
+                cb.mx[k] = key_to_float(acc[12 * (size_t)s + 9 + k]);
+            }
+            segBounds[s] = b;
+            const int dim = hb_maxdim(cb);
+            if (hb_area(b) == 0 || cb.mx[dim] == cb.mn[dim]) delegate[s] = 1;
+            infos[s] = SegInfo{level[s].start, level[s].n, 0, dim, 0, cb.mn[dim], cb.mx[dim]};
+        }
+        GB_CHECK(hipMemcpyAsync(dInfo, infos.data(), infos.size() * sizeof(SegInfo), hipMemcpyHostToDevice, stream), "copy node info");
+        bkeys.assign(kSahBuckets * 6 * (size_t)nSeg, 0u);
+        for (size_t q = 0; q < bkeys.size(); ++q) bkeys[q] = (q % 6) < 3 ? 0xffffffffu : 0u;
+        bcounts.assign(kSahBuckets * (size_t)nSeg, 0);
+        GB_CHECK(hipMemcpyAsync(dBKeys, bkeys.data(), bkeys.size() * sizeof(unsigned), hipMemcpyHostToDevice, stream), "init buckets");
+        GB_CHECK(hipMemcpyAsync(dBCounts, bcounts.data(), bcounts.size() * sizeof(int), hipMemcpyHostToDevice, stream), "init buckets");
+        hipLaunchKernelGGL(k_seg_buckets, dim3(nTiles), dim3(kB), 0, stream, dTiles, dInfo, dPb, dPerm, dBKeys, dBCounts);
+        GB_CHECK(hipMemcpyAsync(bkeys.data(), dBKeys, bkeys.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream), "read buckets");
+        GB_CHECK(hipMemcpyAsync(bcounts.data(), dBCounts, bcounts.size() * sizeof(int), hipMemcpyDeviceToHost, stream), "read buckets");
+        GB_CHECK(hipStreamSynchronize(stream), "sync (buckets)");
+        std::vector<Big> next;
+        for (int s = 0; s < nSeg; ++s) {
+            HostNode &hn = hostNodes[(size_t)level[s].host];
+            if (!delegate[s]) {
+                HBox bb[kSahBuckets];
+                for (int b = 0; b < kSahBuckets; ++b)
+                    for (int k = 0; k < 3; ++k) {
+                        bb[b].mn[k] = key_to_float(bkeys[(kSahBuckets * (size_t)s + b) * 6 + k]);
+                        bb[b].mx[k] = key_to_float(bkeys[(kSahBuckets * (size_t)s + b) * 6 + 3 + k]);
+                    }
+                const SahChoice ch = sah_choose(&bcounts[kSahBuckets * (size_t)s], bb, segBounds[s], level[s].n, maxPrims);
+                if (!ch.split || ch.mid <= 0 || ch.mid >= level[s].n) delegate[s] = 1;
+                else {
+                    infos[s].best = ch.best;
+                    infos[s].mid = ch.mid;
+                }
+            }
+            if (delegate[s]) {
+                // a big node that does not split (coincident centroids / flat bounds): mark it; it
+                // becomes a subtree handled by the wavefront builder, which reaches the same verdict
+                infos[s].mid = 0;
+                infos[s].best = -1;
+                hn.axis = -1;
+                continue;
+            }
+            hn.axis = infos[s].dim;
+        }
+        GB_CHECK(hipMemcpyAsync(dInfo, infos.data(), infos.size() * sizeof(SegInfo), hipMemcpyHostToDevice, stream), "copy splits");
+        GB_CHECK(hipMemsetAsync(dLfFlag, 0, ((size_t)n + 1) * sizeof(int), stream), "memset");
+        GB_CHECK(hipMemsetAsync(dRtFlag, 0, ((size_t)n + 1) * sizeof(int), stream), "memset");
+        hipLaunchKernelGGL(k_seg_flags, dim3(nTiles), dim3(kB), 0, stream, dTiles, dInfo, dPb, dPerm, dLfFlag, dRtFlag);
+        GB_CHECK(rocprim::exclusive_scan(dTmp, scanBytes, dLfFlag, dLfScan, 0, (size_t)n + 1, rocprim::plus<int>(), stream), "scan");
+        GB_CHECK(rocprim::exclusive_scan(dTmp, scanBytes, dRtFlag, dRtScan, 0, (size_t)n + 1, rocprim::plus<int>(), stream), "scan");
+        hipLaunchKernelGGL(k_seg_positions, dim3(nTiles), dim3(kB), 0, stream, dTiles, dInfo, dLfFlag, dLfScan, dRtFlag,
+                           dRtScan, dLfPos, dRtPos);
+        hipLaunchKernelGGL(k_seg_swap, dim3(nTiles), dim3(kB), 0, stream, dTiles, dInfo, dLfScan, dLfPos, dRtPos, dPerm);
+        for (int s = 0; s < nSeg; ++s) {
+            if (delegate[s]) continue;
+            HostNode &hn = hostNodes[(size_t)level[s].host];
+            const int c0 = make_child(level[s].start, infos[s].mid, next);
+            const int c1 = make_child(level[s].start + infos[s].mid, level[s].n - infos[s].mid, next);
+            hostNodes[(size_t)level[s].host].child[0] = c0;  // (hn may dangle after push_back)
+            hostNodes[(size_t)level[s].host].child[1] = c1;
+            (void)hn;
+        }
+        // delegated big nodes: replace the host node by a subtree reference in its parent later
+        for (int s = 0; s < nSeg; ++s)
+            if (delegate[s]) {
+                smallSegs.push_back(SmallSeg{level[s].start, level[s].n, 0});
+                hostNodes[(size_t)level[s].host].child[0] = ~((int)smallSegs.size() - 1);
+                hostNodes[(size_t)level[s].host].child[1] = 0;
+            }
+        level.swap(next);
+    }
+    // k_seg_flags marks delegated nodes' primitives with pred = (bucket <= -1) = false and mid = 0:
+    // every one of them is "right part, predicate false" -> stays in place.
+    out->ms[1] = ms_since(t0);
+
+    // ---- phase B ------------------------------------------------------------------------------------------
+    t0 = std::chrono::steady_clock::now();
+    const int nSmall = (int)smallSegs.size();
+    long poolTotal = 0;
+    for (SmallSeg &sg : smallSegs) {
+        sg.pool = (int)poolTotal;
+        poolTotal += 2L * sg.n - 1;
+    }
+    if (poolTotal >= 0x7fffffffL) {
+        *error = "gpu build: too many nodes";
+        return false;
+    }
+    SmallSeg *dSegs = mem.get<SmallSeg>(nSmall);
+    nnbvh_linear_node *dPool = mem.get<nnbvh_linear_node>((size_t)poolTotal);
+    int *dSegCount = mem.get<int>(nSmall), *dSegDepth = mem.get<int>(nSmall);
+    if (!mem.ok) return false;
+    GB_CHECK(hipMemcpyAsync(dSegs, smallSegs.data(), (size_t)nSmall * sizeof(SmallSeg), hipMemcpyHostToDevice, stream), "copy subtrees");
+    hipLaunchKernelGGL(k_sah_subtrees, dim3(nSmall), dim3(64), 0, stream, dSegs, nSmall, maxPrims, dPb, dPerm, dLfPos,
+                       dRtPos, dPool, dSegCount, dSegDepth, dErr);
+    std::vector<int> segCount((size_t)nSmall), segDepth((size_t)nSmall);
+    GB_CHECK(hipMemcpyAsync(segCount.data(), dSegCount, (size_t)nSmall * sizeof(int), hipMemcpyDeviceToHost, stream), "read counts");
+    GB_CHECK(hipMemcpyAsync(segDepth.data(), dSegDepth, (size_t)nSmall * sizeof(int), hipMemcpyDeviceToHost, stream), "read depths");
+    GB_CHECK(hipMemcpyAsync(&errNow, dErr, sizeof(int), hipMemcpyDeviceToHost, stream), "read error flag");
+    GB_CHECK(hipStreamSynchronize(stream), "sync (subtrees)");
+    if (errNow != 0) {
+        *error = errNow == kErrLeafSize ? "nnbvh_build_create: a leaf would hold more than 65535 primitives"
+                                        : "gpu build: internal error " + std::to_string(errNow);
+        return false;
+    }
+    out->ms[2] = ms_since(t0);
+
+    // ---- phase C: DFS layout (flattenBVH, :505-522) ----------------------------------------------------------
+    t0 = std::chrono::steady_clock::now();
+    std::vector<int> segBase((size_t)nSmall), segBaseDepth((size_t)nSmall);
+    std::vector<UpperNode> upper;
+    int offset = 0, maxDepth = 0;
+    // iterative DFS over the phase-A tree
+    struct Frame {
+        int ref, depth, parentUpper, which;
+    };
+    std::vector<Frame> stack;
+    stack.push_back(Frame{rootRef, 0, -1, 0});
+    while (!stack.empty()) {
+        Frame f = stack.back();
+        stack.pop_back();
+        int ref = f.ref;
+        // a delegated big node stands for its subtree
+        if (ref >= 0 && hostNodes[(size_t)ref].axis < 0) ref = hostNodes[(size_t)ref].child[0];
+        if (f.which == 1) upper[(size_t)f.parentUpper].second = offset;
+        if (ref < 0) {
+            const int sidx = ~ref;
+            segBase[(size_t)sidx] = offset;
+            segBaseDepth[(size_t)sidx] = f.depth;
+            offset += segCount[(size_t)sidx];
+            maxDepth = std::max(maxDepth, f.depth + segDepth[(size_t)sidx]);
+            continue;
+        }
+        const HostNode &hn = hostNodes[(size_t)ref];
+        upper.push_back(UpperNode{offset, 0, hn.axis, f.depth});
+        const int me = (int)upper.size() - 1;
+        ++offset;
+        stack.push_back(Frame{hn.child[1], f.depth + 1, me, 1});  // popped after the whole left subtree
+        stack.push_back(Frame{hn.child[0], f.depth + 1, me, 0});
+    }
+    const int totalNodes = offset;
+    if (maxDepth > 255) {
+        *error = "gpu build: tree deeper than 255 levels";
+        return false;
+    }
+    nnbvh_linear_node *dNodes = mem.get<nnbvh_linear_node>((size_t)totalNodes);
+    unsigned char *dDepthOf = mem.get<unsigned char>((size_t)totalNodes);
+    int *dSegBase = mem.get<int>(nSmall), *dSegBaseDepth = mem.get<int>(nSmall);
+    UpperNode *dUpper = mem.get<UpperNode>(upper.size());
+    nnbvh_prim *dOrdered = mem.get<nnbvh_prim>(n);
+    if (!mem.ok) return false;
+    GB_CHECK(hipMemcpyAsync(dSegBase, segBase.data(), (size_t)nSmall * sizeof(int), hipMemcpyHostToDevice, stream), "copy bases");
+    GB_CHECK(hipMemcpyAsync(dSegBaseDepth, segBaseDepth.data(), (size_t)nSmall * sizeof(int), hipMemcpyHostToDevice, stream), "copy depths");
+    if (!upper.empty())
+        GB_CHECK(hipMemcpyAsync(dUpper, upper.data(), upper.size() * sizeof(UpperNode), hipMemcpyHostToDevice, stream), "copy upper nodes");
+    hipLaunchKernelGGL(k_sah_emit, dim3(nSmall), dim3(kB), 0, stream, dSegs, dSegCount, dSegBase, dSegBaseDepth, dPool, dNodes,
+                       dDepthOf);
+    if (!upper.empty())
+        hipLaunchKernelGGL(k_sah_upper, dim3(grid_all((long)upper.size())), dim3(kB), 0, stream, dUpper, (int)upper.size(),
+                           dNodes, dDepthOf);
+    for (int lvl = maxDepth - 1; lvl >= 0; --lvl)
+        hipLaunchKernelGGL(k_sah_level_bounds, dim3(grid_all(totalNodes)), dim3(kB), 0, stream, totalNodes, lvl, dDepthOf, dNodes);
+    hipLaunchKernelGGL(k_gather_prims, dim3(grid_for(n)), dim3(kB), 0, stream, dPrims, dPerm, n, dOrdered);
+    GB_CHECK(hipGetLastError(), "kernel launch");
+    GB_CHECK(hipStreamSynchronize(stream), "sync after emit");
+    out->ms[3] = ms_since(t0);
+
+    t0 = std::chrono::steady_clock::now();
+    out->nodes.resize((size_t)totalNodes);
+    out->ordered.resize((size_t)n);
+    GB_CHECK(hipMemcpy(out->nodes.data(), dNodes, out->nodes.size() * sizeof(nnbvh_linear_node), hipMemcpyDeviceToHost), "read nodes");
+    GB_CHECK(hipMemcpy(out->ordered.data(), dOrdered, out->ordered.size() * sizeof(nnbvh_prim), hipMemcpyDeviceToHost), "read ordered prims");
+    out->depth = maxDepth;
+    out->n_treelets = nSmall;
+    out->n_unique_codes = (int)upper.size();
+    out->ms[4] = ms_since(t0);
+    return true;
+}
+
 }  // namespace nnbvh

@@ -14,9 +14,10 @@ from nn_bvh_amd import NNBVHError, build_tree, build_tree_gpu, make_prims, scene
 pytestmark = pytest.mark.gpu
 
 
-def same_tree(prims, verts, max_prims=4, prim_bounds=None, what=""):
-    host = build_tree(prims, verts, max_prims, "hlbvh", prim_bounds=prim_bounds)
-    dev = build_tree_gpu(prims, verts, max_prims, prim_bounds=prim_bounds)
+def same_tree(prims, verts, max_prims=4, prim_bounds=None, what="", method="hlbvh"):
+    host = build_tree(prims, verts, max_prims, method, prim_bounds=prim_bounds)
+    dev = build_tree_gpu(prims, verts, max_prims, prim_bounds=prim_bounds, split_method=method)
+    what = f"{what} [{method}]"
     assert len(dev.nodes) == len(host.nodes), f"{what}: {len(dev.nodes)} vs {len(host.nodes)} nodes"
     assert dev.ordered_prims.tobytes() == host.ordered_prims.tobytes(), f"{what}: ordered prims differ"
     if dev.nodes.tobytes() != host.nodes.tobytes():
@@ -121,3 +122,49 @@ def test_scene_blobs(name):
     verts, tris = scene.load_blob(name)
     host = same_tree(make_prims(tris), verts, what=name)
     assert len(host.nodes) > 1000 and host.nodes["nprims"].sum() == len(tris)
+
+
+# ---- SAH on the device: same tree, same leaf order as the host builder (= the reference's) -------------
+@pytest.mark.parametrize("max_prims", [1, 4, 255])
+def test_sah_soup_with_patches(max_prims):
+    verts, prims = ss.random_soup(6000, 1500, 3)
+    same_tree(prims, verts, max_prims, what=f"soup maxprims {max_prims}", method="sah")
+
+
+def test_sah_small_and_degenerate_inputs():
+    for n in (1, 2, 3, 5, 17, 64, 65, 1024, 1025, 2049):
+        verts, prims = ss.random_soup(n, 0, 40 + n)
+        same_tree(prims, verts, what=f"{n} prims", method="sah")
+    verts, prims = ss.coincident_centroids(400, 5)      # one leaf: centroid bounds degenerate
+    same_tree(prims, verts, what="coincident", method="sah")
+    verts, prims = ss.coincident_centroids(3000, 6)     # ... above the wavefront-subtree threshold
+    same_tree(prims, verts, what="coincident big", method="sah")
+    verts, prims = ss.grid_mesh(96, 2)                  # many equal centroids / ties
+    same_tree(prims, verts, what="grid", method="sah")
+
+
+def test_sah_clustered_and_caller_bounds():
+    v1, p1 = ss.random_soup(3000, 0, 6, extent=0.001, size=0.0004)
+    v2, p2 = ss.random_soup(5000, 0, 7, extent=50.0)
+    p2 = p2.copy()
+    p2["v"][:, :3] += len(v1)
+    p2["id"] += len(p1)
+    same_tree(np.concatenate([p1, p2]), np.concatenate([v1, v2]), what="clustered", method="sah")
+    verts, prims = ss.random_soup(3000, 200, 8)
+    rng = np.random.default_rng(4)
+    extra = np.zeros(40, prims.dtype)
+    extra["kind"] = np.where(np.arange(40) % 2 == 0, 2, 3)
+    extra["id"] = len(prims) + np.arange(40)
+    allp = np.concatenate([prims, extra])
+    lo = rng.uniform(-8, 8, (len(allp), 3)).astype(np.float32)
+    pb = np.concatenate([lo, lo + rng.uniform(0.1, 2, (len(allp), 3)).astype(np.float32)], 1)
+    same_tree(allp, verts, prim_bounds=pb, what="with instance/host prims", method="sah")
+
+
+@pytest.mark.parametrize("name", ["killeroos", "coffee_maker", "bathroom", "crown"])
+def test_sah_scene_blobs(name):
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "..", "data", name + ".npz")):
+        pytest.skip(f"data/{name}.npz not present")
+    verts, tris = scene.load_blob(name)
+    host = same_tree(make_prims(tris), verts, what=name, method="sah")
+    assert host.nodes["nprims"].sum() == len(tris)

@@ -19,7 +19,9 @@ DRIVER = textwrap.dedent(r'''
     namespace nnbvh { void set_error(const std::string &m) { std::fprintf(stderr, "err: %s\n", m.c_str()); }
     // the device pipeline lives in bvh_build_gpu.hip, which a CPU-only sanitizer build cannot link
     bool gpu_hlbvh(const nnbvh_prim *, int, const float *, int, const float *, int, int, GpuBuildResult *,
-                   std::string *e) { *e = "no device code in this build"; return false; } }
+                   std::string *e) { *e = "no device code in this build"; return false; }
+    bool gpu_sah(const nnbvh_prim *, int, const float *, int, const float *, int, int, GpuBuildResult *,
+                 std::string *e) { *e = "no device code in this build"; return false; } }
     int main() {
         std::mt19937 rng(3);
         std::uniform_real_distribution<float> U(-1.f, 1.f);
@@ -109,7 +111,9 @@ TSAN_DRIVER = textwrap.dedent(r'''
     namespace nnbvh { void set_error(const std::string &m) { std::fprintf(stderr, "err: %s\n", m.c_str()); }
     // the device pipeline lives in bvh_build_gpu.hip, which a CPU-only sanitizer build cannot link
     bool gpu_hlbvh(const nnbvh_prim *, int, const float *, int, const float *, int, int, GpuBuildResult *,
-                   std::string *e) { *e = "no device code in this build"; return false; } }
+                   std::string *e) { *e = "no device code in this build"; return false; }
+    bool gpu_sah(const nnbvh_prim *, int, const float *, int, const float *, int, int, GpuBuildResult *,
+                 std::string *e) { *e = "no device code in this build"; return false; } }
     int main() {
         // 300 000 primitives: above the 128 K threshold, so sub-trees are built by separate threads
         const int n = 300000;

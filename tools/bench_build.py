@@ -29,15 +29,25 @@ for name in names:
             best = min(best, time.perf_counter() - t0)
         return best * 1e3, res
 
-    ms_sah, _ = timed(lambda: build_tree(prims, verts, 4, "sah"), 1)
     ms_hl, host = timed(lambda: build_tree(prims, verts, 4, "hlbvh"), 3)
+    ms_sah, host_sah = timed(lambda: build_tree(prims, verts, 4, "sah"), 2)
     build_tree_gpu(prims, verts, 4)  # warm-up: module load, allocator
     ms_gpu, dev = timed(lambda: build_tree_gpu(prims, verts, 4), 5)
-    same = dev.nodes.tobytes() == host.nodes.tobytes() and \
-        dev.ordered_prims.tobytes() == host.ordered_prims.tobytes() and dev.depth == host.depth
-    out[name] = {"triangles": int(len(tris)), "hlbvh_nodes": int(len(host.nodes)),
+    build_tree_gpu(prims, verts, 4, split_method="sah")
+    ms_gpu_sah, dev_sah = timed(lambda: build_tree_gpu(prims, verts, 4, split_method="sah"), 5)
+
+    def same(a, b):
+        return bool(a.nodes.tobytes() == b.nodes.tobytes() and
+                    a.ordered_prims.tobytes() == b.ordered_prims.tobytes() and a.depth == b.depth)
+    out[name] = {"triangles": int(len(tris)), "sah_nodes": int(len(host_sah.nodes)),
+                 "hlbvh_nodes": int(len(host.nodes)),
                  "host_sah_ms": round(ms_sah, 1), "host_hlbvh_ms": round(ms_hl, 1),
+                 "gpu_sah_ms_end_to_end": round(ms_gpu_sah, 1),
+                 "gpu_sah_phases_ms (upload, big nodes, subtrees, layout+bounds, download)":
+                     [round(v, 2) for v in dev_sah.gpu_ms],
+                 "gpu_sah_identical_to_host": same(dev_sah, host_sah),
                  "gpu_hlbvh_ms_end_to_end": round(ms_gpu, 1),
-                 "gpu_phases_ms": {k: round(v, 2) for k, v in dev.gpu_ms.items()},
-                 "identical_to_host_hlbvh": bool(same)}
+                 "gpu_hlbvh_phases_ms (upload, device tree, host upper, emit, download)":
+                     [round(v, 2) for v in dev.gpu_ms],
+                 "gpu_hlbvh_identical_to_host": same(dev, host)}
 print(json.dumps(out))
