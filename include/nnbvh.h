@@ -162,6 +162,14 @@ nnbvh_scene *nnbvh_scene_create_instanced(const nnbvh_linear_node *nodes, int n_
  * primitive presents to the top-level builder (TransformedPrimitive::Bounds, primitive.h:94) */
 void nnbvh_transform_bounds(const float render_from_prim[12], const float in_min_max[6],
                             float out_min_max[6]);
+/* Triangles in, traceable scene out, entirely on the device: the tree is built there
+ * (nnbvh_build_create_gpu's builders), baked there into the traversal layout, and never visits the
+ * host.  Same tree and same traversal results as nnbvh_build_create_with_bounds(...,
+ * split_method) + nnbvh_scene_create.  split_method NNBVH_SPLIT_SAH or NNBVH_SPLIT_HLBVH;
+ * triangles, bilinear patches and host-only primitives (instances: nnbvh_scene_create_instanced). */
+nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, const float *verts,
+                                          int n_verts, const float *prim_bounds,
+                                          int max_prims_in_node, int split_method, int device);
 void nnbvh_scene_destroy(nnbvh_scene *s);
 int nnbvh_scene_bounds(const nnbvh_scene *s, float out_min_max[6]);
 /* what the baked device layout looks like: [0]=interior records, [1]=prim-stream slots,

@@ -48,7 +48,7 @@ EXPORTS = [
     "nnbvh_build_create_with_bounds", "nnbvh_wavefront_intersect_closest",
     "nnbvh_wavefront_intersect_shadow", "nnbvh_build_create_gpu", "nnbvh_build_gpu_timing",
     "nnbvh_shading_mesh_create", "nnbvh_shading_mesh_destroy", "nnbvh_triangle_interactions_device",
-    "nnbvh_triangle_interactions",
+    "nnbvh_triangle_interactions", "nnbvh_scene_create_gpu_build",
 ]
 
 _lib = None
@@ -114,6 +114,8 @@ def lib():
     L.nnbvh_build_create_with_bounds.argtypes = [vp, i32, vp, i32, vp, i32, i32]
     L.nnbvh_trace_batches_device.restype = i32
     L.nnbvh_trace_batches_device.argtypes = [vp, vp, i32, vp]
+    L.nnbvh_scene_create_gpu_build.restype = vp
+    L.nnbvh_scene_create_gpu_build.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32]
     L.nnbvh_build_create_gpu.restype = vp
     L.nnbvh_build_create_gpu.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32]
     L.nnbvh_build_gpu_timing.restype = i32

@@ -123,6 +123,40 @@ class BVHAggregate:
         self._init(nodes, ordered_prims, verts, device, None, instances, n_top_nodes)
         return self
 
+    @classmethod
+    def build_on_device(cls, prims, verts, max_prims_in_node=4, split_method="sah", prim_bounds=None,
+                        device=0):
+        """Tree built AND baked on the GPU (nnbvh_scene_create_gpu_build): the tree never visits the
+        host.  Same traversal results as the host-built aggregate; `nodes` / `ordered_prims` are
+        not available on this object."""
+        if split_method not in ("sah", "hlbvh"):
+            raise NNBVHError(f'GPU build supports "sah" and "hlbvh", not "{split_method}"')
+        self = cls.__new__(cls)
+        L = _lib.lib()
+        prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+        verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        pb = None
+        if prim_bounds is not None:
+            pb = np.ascontiguousarray(prim_bounds, np.float32).reshape(len(prims), 6)
+        self.nodes = self.ordered_prims = None
+        self.verts = verts
+        self.device = int(device)
+        self._h = L.nnbvh_scene_create_gpu_build(ptr(prims), len(prims), ptr(verts), len(verts),
+                                                 ptr(pb) if pb is not None else None,
+                                                 int(max_prims_in_node), SPLIT_METHODS[split_method],
+                                                 self.device)
+        if not self._h:
+            raise NNBVHError("nnbvh_scene_create_gpu_build: " + _lib.last_error())
+        self._read_info()
+        return self
+
+    def _read_info(self):
+        info = np.zeros(6, np.int64)
+        check(_lib.lib().nnbvh_scene_info(self._h, ptr(info)), "nnbvh_scene_info")
+        self.info = {"interior_records": int(info[0]), "prim_slots": int(info[1]),
+                     "depth": int(info[2]), "device_bytes": int(info[3]),
+                     "grid_blocks": int(info[4]), "stack_window": int(info[5])}
+
     def _init(self, nodes, ordered_prims, verts, device, depth, instances=None, n_top_nodes=None):
         L = _lib.lib()
         self.nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
@@ -141,11 +175,7 @@ class BVHAggregate:
                                            self.device)
         if not self._h:
             raise NNBVHError("nnbvh_scene_create: " + _lib.last_error())
-        info = np.zeros(6, np.int64)
-        check(L.nnbvh_scene_info(self._h, ptr(info)), "nnbvh_scene_info")
-        self.info = {"interior_records": int(info[0]), "prim_slots": int(info[1]),
-                     "depth": int(info[2]), "device_bytes": int(info[3]),
-                     "grid_blocks": int(info[4]), "stack_window": int(info[5])}
+        self._read_info()
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1,0 +1,215 @@
+// bvh_bake.hip — the traversal kernels' data layout (nnbvh_internal.h) produced on the device from
+// a device-resident LinearBVHNode array + leaf-ordered primitive table: the counterpart of the
+// host baking in bvh_capi.cpp (create_scene), bit for bit, for scenes of triangles, bilinear
+// patches and host-only primitives.  With the device builders (bvh_build_gpu.hip) a scene goes
+// from triangles to traceable without its tree ever visiting the host.
+//
+// Four streaming passes over 24-32-B records plus three prefix sums; HBM-bound.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "bvh_build_gpu.h"
+#include "nnbvh_internal.h"
+
+namespace nnbvh {
+namespace {
+
+constexpr int kBk = 256;
+
+__global__ __launch_bounds__(kBk) void k_bake_slot_counts(const nnbvh_prim *__restrict__ prims, int n,
+                                                         int *__restrict__ slots, int *flags) {
+    const int i = blockIdx.x * kBk + threadIdx.x;
+    if (i >= n) return;
+    const int kind = prims[i].kind;
+    int c = 3;  // triangle, host-only primitive
+    if (kind == NNBVH_PRIM_BILINEAR_PATCH) c = 4;
+    else if (kind == NNBVH_PRIM_HOST) atomicOr(flags, 1);
+    else if (kind != NNBVH_PRIM_TRIANGLE) atomicOr(flags, 2);  // instances are not baked here
+    slots[i] = c;
+}
+
+__global__ __launch_bounds__(kBk) void k_bake_node_flags(const nnbvh_linear_node *__restrict__ nodes, int n,
+                                                        int *__restrict__ interior,
+                                                        unsigned char *__restrict__ leafLast) {
+    const int i = blockIdx.x * kBk + threadIdx.x;
+    if (i >= n) return;
+    const nnbvh_linear_node nd = nodes[i];
+    interior[i] = nd.nprims == 0 ? 1 : 0;
+    if (nd.nprims != 0) leafLast[nd.offset + nd.nprims - 1] = 1;
+}
+
+// DifferenceOfProducts (util/math.h:569-575) and the degenerate-triangle test of shapes.cpp:176-177
+__device__ __forceinline__ float bake_dop(float a, float b, float c, float d) {
+    const float cd = c * d;
+    const float diff = __builtin_fmaf(a, b, -cd);
+    const float err = __builtin_fmaf(-c, d, cd);
+    return diff + err;
+}
+
+__global__ __launch_bounds__(kBk) void k_bake_stream(const nnbvh_prim *__restrict__ prims, int n,
+                                                    const float *__restrict__ verts,
+                                                    const int *__restrict__ slotOf,
+                                                    const unsigned char *__restrict__ leafLast,
+                                                    float4 *__restrict__ stream) {
+    const int i = blockIdx.x * kBk + threadIdx.x;
+    if (i >= n) return;
+    const nnbvh_prim p = prims[i];
+    float4 *s = stream + slotOf[i];
+    unsigned flags = leafLast[i] ? kPrimLast : 0u;
+    if (p.kind == NNBVH_PRIM_HOST) {
+        flags |= kPrimHost;
+        s[0] = make_float4(0, 0, 0, __int_as_float(p.id));
+        s[1] = make_float4(0, 0, 0, __uint_as_float(flags));
+        s[2] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const int nv = p.kind == NNBVH_PRIM_BILINEAR_PATCH ? 4 : 3;
+    float v[4][3];
+    for (int j = 0; j < nv; ++j)
+        for (int k = 0; k < 3; ++k) v[j][k] = verts[3 * (long)p.v[j] + k];
+    if (nv == 4) {
+        flags |= kPrimPatch;
+    } else {
+        const float ax = v[2][0] - v[0][0], ay = v[2][1] - v[0][1], az = v[2][2] - v[0][2];
+        const float bx = v[1][0] - v[0][0], by = v[1][1] - v[0][1], bz = v[1][2] - v[0][2];
+        const float cx = bake_dop(ay, bz, az, by), cy = bake_dop(az, bx, ax, bz), cz = bake_dop(ax, by, ay, bx);
+        if (cx * cx + cy * cy + cz * cz == 0.0f) flags |= kPrimDegenerate;
+    }
+    s[0] = make_float4(v[0][0], v[0][1], v[0][2], __int_as_float(p.id));
+    s[1] = make_float4(v[1][0], v[1][1], v[1][2], __uint_as_float(flags));
+    s[2] = make_float4(v[2][0], v[2][1], v[2][2], 0);
+    if (nv == 4) s[3] = make_float4(v[3][0], v[3][1], v[3][2], 0);
+}
+
+__device__ __forceinline__ int bake_ref(const nnbvh_linear_node &nd, int index, const int *ord, const int *slotOf) {
+    return nd.nprims == 0 ? ord[index] : ~slotOf[nd.offset];
+}
+
+__global__ __launch_bounds__(kBk) void k_bake_wide(const nnbvh_linear_node *__restrict__ nodes, int n,
+                                                  const int *__restrict__ ord, const int *__restrict__ slotOf,
+                                                  float4 *__restrict__ wide) {
+    const int i = blockIdx.x * kBk + threadIdx.x;
+    if (i >= n) return;
+    const nnbvh_linear_node nd = nodes[i];
+    if (nd.nprims != 0) return;
+    const nnbvh_linear_node c0 = nodes[i + 1], c1 = nodes[nd.offset];
+    float4 *w = wide + 4 * (long)ord[i];
+    w[0] = make_float4(c0.pmin[0], c0.pmin[1], c0.pmin[2], c0.pmax[0]);
+    w[1] = make_float4(c0.pmax[1], c0.pmax[2], c1.pmin[0], c1.pmin[1]);
+    w[2] = make_float4(c1.pmin[2], c1.pmax[0], c1.pmax[1], c1.pmax[2]);
+    w[3] = make_float4(__int_as_float(bake_ref(c0, i + 1, ord, slotOf)), __int_as_float(bake_ref(c1, nd.offset, ord, slotOf)),
+                       __int_as_float((int)nd.axis), __int_as_float(0));
+}
+
+struct Scratch {
+    void *ptrs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int n = 0;
+    void *get(size_t bytes) {
+        void *p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+        ptrs[n++] = p;
+        return p;
+    }
+    ~Scratch() {
+        for (int i = 0; i < n; ++i) (void)hipFree(ptrs[i]);
+    }
+};
+
+}  // namespace
+
+#define BK_CHECK(expr, what)                                                            \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            *error = std::string("device bake: ") + what + ": " + hipGetErrorString(e_); \
+            return false;                                                               \
+        }                                                                               \
+    } while (0)
+
+bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int n_prims, const void *d_verts_,
+                    int device, BakedScene *out, std::string *error) {
+    const auto *dNodes = (const nnbvh_linear_node *)d_nodes_;
+    const auto *dPrims = (const nnbvh_prim *)d_prims_;
+    const auto *dVerts = (const float *)d_verts_;
+    BK_CHECK(hipSetDevice(device), "hipSetDevice");
+    hipStream_t stream = nullptr;
+    Scratch sc;
+    int *dSlots = (int *)sc.get(((size_t)n_prims + 1) * sizeof(int));
+    int *dSlotOf = (int *)sc.get(((size_t)n_prims + 1) * sizeof(int));
+    int *dInterior = (int *)sc.get(((size_t)n_nodes + 1) * sizeof(int));
+    int *dOrd = (int *)sc.get(((size_t)n_nodes + 1) * sizeof(int));
+    unsigned char *dLeafLast = (unsigned char *)sc.get((size_t)n_prims);
+    int *dFlags = (int *)sc.get(sizeof(int));
+    size_t scanBytes = 0;
+    const size_t scanN = (size_t)std::max(n_prims, n_nodes) + 1;
+    BK_CHECK(rocprim::exclusive_scan(nullptr, scanBytes, dSlots, dSlotOf, 0, scanN, rocprim::plus<int>(), stream),
+             "scan (size query)");
+    void *dTmp = sc.get(scanBytes);
+    if (!dSlots || !dSlotOf || !dInterior || !dOrd || !dLeafLast || !dFlags || !dTmp) {
+        *error = "device bake: hipMalloc failed";
+        return false;
+    }
+    BK_CHECK(hipMemsetAsync(dSlots, 0, ((size_t)n_prims + 1) * sizeof(int), stream), "memset");
+    BK_CHECK(hipMemsetAsync(dInterior, 0, ((size_t)n_nodes + 1) * sizeof(int), stream), "memset");
+    BK_CHECK(hipMemsetAsync(dLeafLast, 0, (size_t)n_prims, stream), "memset");
+    BK_CHECK(hipMemsetAsync(dFlags, 0, sizeof(int), stream), "memset");
+    const int gp = (n_prims + kBk - 1) / kBk, gn = (n_nodes + kBk - 1) / kBk;
+    hipLaunchKernelGGL(k_bake_slot_counts, dim3(gp), dim3(kBk), 0, stream, dPrims, n_prims, dSlots, dFlags);
+    hipLaunchKernelGGL(k_bake_node_flags, dim3(gn), dim3(kBk), 0, stream, dNodes, n_nodes, dInterior, dLeafLast);
+    BK_CHECK(rocprim::exclusive_scan(dTmp, scanBytes, dSlots, dSlotOf, 0, (size_t)n_prims + 1, rocprim::plus<int>(), stream),
+             "scan slots");
+    BK_CHECK(rocprim::exclusive_scan(dTmp, scanBytes, dInterior, dOrd, 0, (size_t)n_nodes + 1, rocprim::plus<int>(), stream),
+             "scan interior nodes");
+    int nSlots = 0, nInterior = 0, flags = 0;
+    nnbvh_linear_node root;
+    BK_CHECK(hipMemcpyAsync(&nSlots, dSlotOf + n_prims, sizeof(int), hipMemcpyDeviceToHost, stream), "read slot count");
+    BK_CHECK(hipMemcpyAsync(&nInterior, dOrd + n_nodes, sizeof(int), hipMemcpyDeviceToHost, stream), "read interior count");
+    BK_CHECK(hipMemcpyAsync(&flags, dFlags, sizeof(int), hipMemcpyDeviceToHost, stream), "read flags");
+    BK_CHECK(hipMemcpyAsync(&root, dNodes, sizeof root, hipMemcpyDeviceToHost, stream), "read root");
+    BK_CHECK(hipStreamSynchronize(stream), "sync");
+    if (flags & 2) {
+        *error = "device bake: instance primitives are baked on the host (nnbvh_scene_create_instanced)";
+        return false;
+    }
+    if (nSlots <= 0 || nSlots >= 0x7ffffffe) {
+        *error = "device bake: primitive stream exceeds 2^31 slots";
+        return false;
+    }
+    void *dWide = nullptr, *dStream = nullptr;
+    BK_CHECK(hipMalloc(&dWide, (size_t)std::max(nInterior, 1) * sizeof(WideNode)), "hipMalloc(nodes)");
+    if (hipMalloc(&dStream, (size_t)nSlots * 16) != hipSuccess) {
+        (void)hipFree(dWide);
+        *error = "device bake: hipMalloc(prims) failed";
+        return false;
+    }
+    hipLaunchKernelGGL(k_bake_stream, dim3(gp), dim3(kBk), 0, stream, dPrims, n_prims, dVerts, dSlotOf, dLeafLast,
+                       (float4 *)dStream);
+    hipLaunchKernelGGL(k_bake_wide, dim3(gn), dim3(kBk), 0, stream, dNodes, n_nodes, dOrd, dSlotOf, (float4 *)dWide);
+    int rootSlot = 0;
+    if (root.nprims != 0)
+        (void)hipMemcpyAsync(&rootSlot, dSlotOf + root.offset, sizeof(int), hipMemcpyDeviceToHost, stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        (void)hipFree(dWide);
+        (void)hipFree(dStream);
+        *error = std::string("device bake: ") + hipGetErrorString(e);
+        return false;
+    }
+    out->d_wide = dWide;
+    out->d_prims = dStream;
+    out->n_interior = nInterior;
+    out->n_slots = nSlots;
+    out->root_ref = root.nprims == 0 ? 0 : ~rootSlot;  // interior root = record 0
+    std::memcpy(out->bounds, root.pmin, 12);
+    std::memcpy(out->bounds + 3, root.pmax, 12);
+    out->has_host_prims = flags & 1;
+    return true;
+}
+
+}  // namespace nnbvh

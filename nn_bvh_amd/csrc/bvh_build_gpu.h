@@ -32,6 +32,11 @@ struct GpuBuildResult {
     // device emit, device->host copies
     double ms[5] = {0, 0, 0, 0, 0};
     int n_treelets = 0, n_unique_codes = 0;
+    // keep_on_device (in): do not download; hand the device arrays to the caller instead (who frees
+    // them with hipFree): LinearBVHNode[total_nodes], leaf-ordered nnbvh_prim[n_prims], float3 verts
+    bool keep_on_device = false;
+    void *d_nodes = nullptr, *d_ordered = nullptr, *d_verts = nullptr;
+    int total_nodes = 0;
 };
 // prim_bounds may be NULL when every primitive is a triangle or a bilinear patch.
 bool gpu_hlbvh(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
@@ -43,5 +48,19 @@ bool gpu_hlbvh(const nnbvh_prim *prims, int n_prims, const float *verts, int n_v
 // n_treelets = subtrees built by wavefronts, n_unique_codes = nodes built breadth-first.
 bool gpu_sah(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts, const float *prim_bounds,
              int max_prims_in_node, int device, GpuBuildResult *out, std::string *error);
+
+// Device-side counterpart of nnbvh_scene_create's baking (bvh_capi.cpp): the 64-B "both children"
+// records and the 16-B-slot primitive stream, straight from device-resident build output.  Triangles,
+// bilinear patches and host-only primitives (no instances).
+struct BakedScene {
+    void *d_wide = nullptr, *d_prims = nullptr;  // float4 arrays, owned by the caller afterwards
+    int n_interior = 0;
+    long n_slots = 0;
+    int root_ref = 0;
+    float bounds[6] = {0, 0, 0, 0, 0, 0};
+    int has_host_prims = 0;
+};
+bool bake_on_device(const void *d_nodes, int n_nodes, const void *d_ordered_prims, int n_prims, const void *d_verts,
+                    int device, BakedScene *out, std::string *error);
 
 }  // namespace nnbvh

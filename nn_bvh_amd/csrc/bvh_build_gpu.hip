@@ -437,6 +437,13 @@ __global__ __launch_bounds__(kB) void k_gather_prims(const nnbvh_prim *__restric
         ordered[i] = prims[idxSorted[i]];
 }
 
+__global__ __launch_bounds__(kB) void k_scatter_nodes(const int *__restrict__ index,
+                                                      const nnbvh_linear_node *__restrict__ src, int n,
+                                                      nnbvh_linear_node *__restrict__ nodes) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i < n) nodes[index[i]] = src[i];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 struct DevMem {  // frees everything it handed out
     std::vector<void *> ptrs;
@@ -454,8 +461,13 @@ struct DevMem {  // frees everything it handed out
         ptrs.push_back(p);
         return (T *)p;
     }
+    void release(void *p) {  // ownership goes to the caller
+        for (void *&q : ptrs)
+            if (q == p) q = nullptr;
+    }
     ~DevMem() {
-        for (void *p : ptrs) (void)hipFree(p);
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
     }
 };
 
@@ -632,18 +644,40 @@ bool gpu_hlbvh(const nnbvh_prim *prims, int n, const float *verts, int n_verts,
     out->ms[3] = ms_since(t0);
 
     t0 = std::chrono::steady_clock::now();
+    out->depth = 0;
+    GB_CHECK(hipMemcpy(&out->depth, dMaxDepth, sizeof(int), hipMemcpyDeviceToHost), "read depth");
+    out->total_nodes = up.total_nodes;
+    if (out->keep_on_device) {
+        // upper nodes join the device array; nothing else leaves the device
+        if (!up.upper_index.empty()) {
+            int *dUi = mem.get<int>(up.upper_index.size());
+            nnbvh_linear_node *dUn = mem.get<nnbvh_linear_node>(up.upper_nodes.size());
+            if (!mem.ok) return false;
+            GB_CHECK(hipMemcpy(dUi, up.upper_index.data(), up.upper_index.size() * sizeof(int), hipMemcpyHostToDevice), "copy upper");
+            GB_CHECK(hipMemcpy(dUn, up.upper_nodes.data(), up.upper_nodes.size() * sizeof(nnbvh_linear_node), hipMemcpyHostToDevice), "copy upper");
+            hipLaunchKernelGGL(k_scatter_nodes, dim3(grid_all((long)up.upper_index.size())), dim3(kB), 0, stream, dUi, dUn,
+                               (int)up.upper_index.size(), dNodes);
+            GB_CHECK(hipStreamSynchronize(stream), "sync (upper nodes)");
+        }
+        out->d_nodes = dNodes;
+        out->d_ordered = dOrdered;
+        out->d_verts = dVerts;
+        mem.release(dNodes);
+        mem.release(dOrdered);
+        mem.release(dVerts);
+        out->ms[4] = ms_since(t0);
+        return true;
+    }
     out->nodes.resize((size_t)up.total_nodes);
     out->ordered.resize((size_t)n);
     GB_CHECK(hipMemcpy(out->nodes.data(), dNodes, out->nodes.size() * sizeof(nnbvh_linear_node), hipMemcpyDeviceToHost),
              "read nodes");
     GB_CHECK(hipMemcpy(out->ordered.data(), dOrdered, out->ordered.size() * sizeof(nnbvh_prim), hipMemcpyDeviceToHost),
              "read ordered prims");
-    GB_CHECK(hipMemcpy(&out->depth, dMaxDepth, sizeof(int), hipMemcpyDeviceToHost), "read depth");
     for (size_t k = 0; k < up.upper_index.size(); ++k) out->nodes[(size_t)up.upper_index[k]] = up.upper_nodes[k];
     out->ms[4] = ms_since(t0);
     return true;
 }
-
 
 // =================================================================================================
 // SAH build on the device: buildRecursive's SAH branch (aggregates.cpp:192-387) with the SAME tree
@@ -670,7 +704,7 @@ bool gpu_hlbvh(const nnbvh_prim *prims, int n, const float *verts, int n_verts,
 namespace {
 
 constexpr int kSahBuckets = 12;
-constexpr int kSmallSegment = 1024;
+constexpr int kSmallSegmentDefault = 1024;
 constexpr int kTile = 2048;
 
 struct HBox {
@@ -1147,6 +1181,8 @@ bool gpu_sah(const nnbvh_prim *prims, int n, const float *verts, int n_verts, co
         ~Restore() { (void)hipSetDevice(d); }
     } restore{prev};
     const int maxPrims = std::min(255, max_prims_in_node);
+    int kSmallSegment = kSmallSegmentDefault;  // speed only: where breadth-first hands over to wavefronts
+    if (const char *e = std::getenv("NNBVH_SAH_SMALL")) kSmallSegment = std::max(2, std::atoi(e));
     hipStream_t stream = nullptr;
     DevMem mem;
     mem.error = error;
@@ -1429,10 +1465,20 @@ bool gpu_sah(const nnbvh_prim *prims, int n, const float *verts, int n_verts, co
     out->ms[3] = ms_since(t0);
 
     t0 = std::chrono::steady_clock::now();
-    out->nodes.resize((size_t)totalNodes);
-    out->ordered.resize((size_t)n);
-    GB_CHECK(hipMemcpy(out->nodes.data(), dNodes, out->nodes.size() * sizeof(nnbvh_linear_node), hipMemcpyDeviceToHost), "read nodes");
-    GB_CHECK(hipMemcpy(out->ordered.data(), dOrdered, out->ordered.size() * sizeof(nnbvh_prim), hipMemcpyDeviceToHost), "read ordered prims");
+    out->total_nodes = totalNodes;
+    if (out->keep_on_device) {
+        out->d_nodes = dNodes;
+        out->d_ordered = dOrdered;
+        out->d_verts = dVerts;
+        mem.release(dNodes);
+        mem.release(dOrdered);
+        mem.release(dVerts);
+    } else {
+        out->nodes.resize((size_t)totalNodes);
+        out->ordered.resize((size_t)n);
+        GB_CHECK(hipMemcpy(out->nodes.data(), dNodes, out->nodes.size() * sizeof(nnbvh_linear_node), hipMemcpyDeviceToHost), "read nodes");
+        GB_CHECK(hipMemcpy(out->ordered.data(), dOrdered, out->ordered.size() * sizeof(nnbvh_prim), hipMemcpyDeviceToHost), "read ordered prims");
+    }
     out->depth = maxDepth;
     out->n_treelets = nSmall;
     out->n_unique_codes = (int)upper.size();

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "bvh_trace.h"
+#include "bvh_build_gpu.h"
 #include "interaction.h"
 #include "wavefront.h"
 
@@ -76,6 +77,7 @@ struct nnbvh_scene {
     int has_host_prims = 0;
     int int_repeat = 3;
     int max_grid_threads = 0;
+    double build_ms[1] = {0};  // device build time of nnbvh_scene_create_gpu_build
     std::mutex mu;
     std::map<hipStream_t, Workspace> workspaces;
     // fork/join machinery of nnbvh_trace_batches_device
@@ -369,6 +371,73 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     if (const char *e = std::getenv("NNBVH_XCD_QUEUES")) nnbvh_scene_set_option(s, "xcd_queues", atoi(e));
     if (const char *e = std::getenv("NNBVH_REFILL_WEIGHT")) nnbvh_scene_set_option(s, "refill_weight", atoi(e));
     if (const char *e = std::getenv("NNBVH_PRIM_WEIGHT")) nnbvh_scene_set_option(s, "prim_weight", atoi(e));
+    return s;
+}
+
+// Triangles in, traceable scene out, without the tree leaving the device: device build
+// (bvh_build_gpu.hip) + device bake (bvh_bake.hip).  Same tree, same baked arrays, hence the same
+// results as nnbvh_build_create + nnbvh_scene_create.
+nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, const float *verts,
+                                          int n_verts, const float *prim_bounds,
+                                          int max_prims_in_node, int split_method, int device) {
+    if (!prims || !verts || n_prims <= 0 || n_verts <= 0) {
+        set_error("scene_create_gpu_build: empty primitive or vertex array");
+        return nullptr;
+    }
+    if (split_method != NNBVH_SPLIT_SAH && split_method != NNBVH_SPLIT_HLBVH) {
+        set_error("scene_create_gpu_build: only the sah and hlbvh split methods are built on the device");
+        return nullptr;
+    }
+    int n_dev = nnbvh_device_count();
+    if (n_dev <= 0 || device < 0 || device >= n_dev) {
+        set_error("scene_create_gpu_build: no usable HIP device (this library has no CPU fallback)");
+        return nullptr;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return nullptr;
+    GpuBuildResult r;
+    r.keep_on_device = true;
+    std::string err;
+    const bool built = split_method == NNBVH_SPLIT_SAH
+                           ? gpu_sah(prims, n_prims, verts, n_verts, prim_bounds, max_prims_in_node, device, &r, &err)
+                           : gpu_hlbvh(prims, n_prims, verts, n_verts, prim_bounds, max_prims_in_node, device, &r, &err);
+    if (!built) {
+        set_error(err);
+        return nullptr;
+    }
+    BakedScene b;
+    bool ok = r.depth <= kMaxStack;
+    if (!ok) err = "scene_create: tree deeper than the 64-entry traversal stack";
+    ok = ok && bake_on_device(r.d_nodes, r.total_nodes, r.d_ordered, n_prims, r.d_verts, device, &b, &err);
+    for (void *p : {r.d_nodes, r.d_ordered, r.d_verts})
+        if (p) (void)hipFree(p);
+    if (!ok) {
+        set_error(err);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) {
+        (void)hipFree(b.d_wide);
+        (void)hipFree(b.d_prims);
+        return nullptr;
+    }
+    auto *s = new nnbvh_scene;
+    s->device = device;
+    s->n_cus = prop.multiProcessorCount;
+    s->n_interior = b.n_interior;
+    s->n_slots = b.n_slots;
+    s->depth = r.depth;
+    std::memcpy(s->bounds, b.bounds, sizeof b.bounds);
+    s->root_ref = b.root_ref;
+    s->instanced = 0;
+    s->has_host_prims = b.has_host_prims;
+    s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
+    s->d_wide = (float4 *)b.d_wide;
+    s->d_prims = (float4 *)b.d_prims;
+    s->device_bytes = (size_t)std::max(b.n_interior, 1) * sizeof(WideNode) + (size_t)b.n_slots * 16;
+    if (hipMalloc((void **)&s->d_stats, 16 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(s->d_stats, 0, 16 * sizeof(unsigned long long));
+    s->build_ms[0] = r.ms[0] + r.ms[1] + r.ms[2] + r.ms[3] + r.ms[4];
     return s;
 }
 

@@ -168,3 +168,67 @@ def test_sah_scene_blobs(name):
     verts, tris = scene.load_blob(name)
     host = same_tree(make_prims(tris), verts, what=name, method="sah")
     assert host.nodes["nprims"].sum() == len(tris)
+
+
+# ---- build + bake on the device: the tree never visits the host -----------------------------------------
+def traces_identically(prims, verts, rays, method, prim_bounds=None, what=""):
+    from nn_bvh_amd import BVHAggregate
+    tree = build_tree(prims, verts, 4, method, prim_bounds=prim_bounds)
+    host = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+    dev = BVHAggregate.build_on_device(prims, verts, 4, method, prim_bounds=prim_bounds)
+    for key in ("interior_records", "prim_slots", "depth", "device_bytes"):
+        assert dev.info[key] == host.info[key], f"{what}: {key} {dev.info[key]} vs {host.info[key]}"
+    assert np.array_equal(np.concatenate(dev.Bounds()), np.concatenate(host.Bounds()))
+    a, b = host.Intersect(rays), dev.Intersect(rays)
+    assert a.tobytes() == b.tobytes(), f"{what}: closest-hit records differ"
+    for x, y in zip(host.IntersectP(rays, counts=True), dev.IntersectP(rays, counts=True)):
+        assert np.array_equal(x, y), f"{what}: any-hit results differ"
+    host.close()
+    dev.close()
+    return a
+
+
+@pytest.mark.parametrize("method", ["sah", "hlbvh"])
+def test_device_built_and_baked_scene_traces_identically(method):
+    verts, prims = ss.random_soup(5000, 800, 21)
+    rays = np.concatenate([scene.random_rays(20000, verts.min(0) - 2, verts.max(0) + 2, 22),
+                           ss.edge_case_rays(verts, prims, 23)])
+    hits = traces_identically(prims, verts, rays, method, what=f"soup {method}")
+    assert (hits["prim"] >= 0).mean() > 0.2
+    # degenerate triangles (flag computed at bake time) and a single-leaf tree
+    v2, p2 = ss.random_soup(300, 0, 24)
+    v2 = v2.copy()
+    v2[3:6] = v2[3]            # triangle 1 collapses to a point
+    v2[8] = v2[7]              # triangle 2 to a segment
+    traces_identically(p2, v2, scene.random_rays(4000, v2.min(0) - 1, v2.max(0) + 1, 25), method, what="degenerate")
+    v1, p1 = ss.random_soup(1, 0, 26)
+    traces_identically(p1, v1, scene.random_rays(500, v1.min(0) - 1, v1.max(0) + 1, 27), method, what="one prim")
+
+
+def test_device_built_scene_with_host_only_primitives():
+    verts, prims = ss.random_soup(3000, 100, 31)
+    rng = np.random.default_rng(5)
+    extra = np.zeros(25, prims.dtype)
+    extra["kind"] = 3
+    extra["id"] = len(prims) + np.arange(25)
+    allp = np.concatenate([prims, extra])
+    lo = rng.uniform(-8, 8, (len(allp), 3)).astype(np.float32)
+    pb = np.concatenate([lo, lo + rng.uniform(0.5, 2, (len(allp), 3)).astype(np.float32)], 1)
+    rays = scene.random_rays(15000, verts.min(0) - 2, verts.max(0) + 2, 32)
+    hits = traces_identically(allp, verts, rays, "sah", prim_bounds=pb, what="host prims")
+    assert (hits["instance"] == -1).any()
+    # instance primitives are not baked on the device
+    from nn_bvh_amd import BVHAggregate
+    allp2 = allp.copy()
+    allp2["kind"][-1] = 2
+    with pytest.raises(NNBVHError, match="instance"):
+        BVHAggregate.build_on_device(allp2, verts, prim_bounds=pb)
+
+
+def test_device_built_crown_traces_identically():
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "..", "data", "crown.npz")):
+        pytest.skip("data/crown.npz not present")
+    verts, tris = scene.load_blob("crown")
+    rays = scene.camera_rays("crown", subsample=4)
+    hits = traces_identically(make_prims(tris), verts, rays, "sah", what="crown")
+    assert abs(hits["nodes_visited"].mean() - 99.4) < 1.0
