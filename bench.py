@@ -63,9 +63,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="crown")
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel traced per step")
-    ap.add_argument("--tree", default="sah", choices=["sah", "hlbvh", "middle", "equal", "nn"],
-                    help="tree builder: pbrt split methods, or nn = greedy-SAH top levels of "
-                         "machine_learning/nn_BVH.py finished by SAH and baked (BASELINE config 5)")
+    ap.add_argument("--tree", default="sah", choices=["sah", "hlbvh", "middle", "equal", "nn", "sah_gpu", "hlbvh_gpu"],
+                    help="tree builder: pbrt split methods (host), nn = greedy-SAH top levels of "
+                         "machine_learning/nn_BVH.py finished by SAH and baked (BASELINE config 5), "
+                         "*_gpu = the same sah / hlbvh tree built and baked on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wavefront", action="store_true",
                     help="also time the step through the wavefront-queue entry points")
@@ -113,9 +114,18 @@ def main():
         from nn_bvh_amd.aggregate import BuiltTree
         (nn_nodes, nn_ordered), _ = nn_tree.greedy_sah_tree(verts, tris, levels=4)
         tree = BuiltTree(nn_nodes, nn_ordered, -1)
+    elif args.tree in ("sah_gpu", "hlbvh_gpu"):
+        # built and baked on the device; the host copy of the same tree only serves the oracle leg
+        tree = build_tree(prims, verts, 4, args.tree[:-4])
     else:
         tree = build_tree(prims, verts, 4, args.tree)
-    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, device=local_rank)
+    if args.tree in ("sah_gpu", "hlbvh_gpu"):
+        t_dev = time.time()
+        agg = BVHAggregate.build_on_device(prims, verts, 4, args.tree[:-4], device=local_rank)
+        if rank == 0:
+            log(f"[bench] scene built and baked on the device in {(time.time() - t_dev) * 1e3:.0f} ms")
+    else:
+        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, device=local_rank)
     tree.depth = agg.info["depth"]
     if rank == 0:
         log(f"[bench] scene: {source}; {len(tris)} tris, {len(tree.nodes)} nodes, depth {tree.depth}; "

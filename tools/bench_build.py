@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-from nn_bvh_amd import build_tree, build_tree_gpu, make_prims, scene  # noqa: E402
+from nn_bvh_amd import BVHAggregate, build_tree, build_tree_gpu, make_prims, scene  # noqa: E402
 
 names = sys.argv[1:] or ["killeroos", "coffee_maker", "bathroom", "crown"]
 out = {}
@@ -39,7 +39,19 @@ for name in names:
     def same(a, b):
         return bool(a.nodes.tobytes() == b.nodes.tobytes() and
                     a.ordered_prims.tobytes() == b.ordered_prims.tobytes() and a.depth == b.depth)
+    def scene_host():
+        t = build_tree(prims, verts, 4, "sah")
+        BVHAggregate.from_tree(t.nodes, t.ordered_prims, verts).close()
+
+    def scene_device():
+        BVHAggregate.build_on_device(prims, verts, 4, "sah").close()
+
+    ms_scene_host, _ = timed(scene_host, 2)
+    scene_device()
+    ms_scene_dev, _ = timed(scene_device, 5)
     out[name] = {"triangles": int(len(tris)), "sah_nodes": int(len(host_sah.nodes)),
+                 "scene_create_ms_host_build_and_bake_sah": round(ms_scene_host, 1),
+                 "scene_create_ms_device_build_and_bake_sah": round(ms_scene_dev, 1),
                  "hlbvh_nodes": int(len(host.nodes)),
                  "host_sah_ms": round(ms_sah, 1), "host_hlbvh_ms": round(ms_hl, 1),
                  "gpu_sah_ms_end_to_end": round(ms_gpu_sah, 1),
