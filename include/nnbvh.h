@@ -127,7 +127,7 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
 /* Tree construction on the GPU (`device`), split_method NNBVH_SPLIT_SAH or NNBVH_SPLIT_HLBVH; the
  * result (nodes, leaf-ordered primitives, depth) is byte-identical to
  * nnbvh_build_create_with_bounds(..., split_method), i.e. to the reference's tree.
- *   SAH   (buildRecursive, aggregates.cpp:192-387): nodes above 1024 primitives breadth-first with
+ *   SAH   (buildRecursive, aggregates.cpp:192-387): nodes above 256 primitives breadth-first with
  *         whole-grid kernels, every smaller subtree by one wavefront; std::partition's exact
  *         element order is reproduced from ballots / prefix sums.
  *   HLBVH (buildHLBVH, aggregates.cpp:389-503 with treelets emitted in Morton order): Morton codes,

@@ -695,7 +695,7 @@ bool gpu_hlbvh(const nnbvh_prim *prims, int n, const float *verts, int n_verts,
 //     so a node is partitioned in parallel with the sequential algorithm's exact result;
 //   * stored bounds: a leaf's are the in-order fold over its primitives, an interior node's the
 //     fold child 0 then child 1 (:371-373) — done after the layout, level by level from the leaves.
-// Phase A: nodes with more than kSmallSegment primitives, breadth-first, whole-grid kernels per
+// Phase A: nodes with more than kSmallSegment (256) primitives, breadth-first, whole-grid kernels per
 //          level (tile = 2048 primitives of one node), the 12-bucket decision on the host (a few
 //          thousand nodes in total).
 // Phase B: every remaining subtree is built depth-first by ONE wavefront (explicit stack in LDS,
@@ -704,7 +704,7 @@ bool gpu_hlbvh(const nnbvh_prim *prims, int n, const float *verts, int n_verts,
 namespace {
 
 constexpr int kSahBuckets = 12;
-constexpr int kSmallSegmentDefault = 1024;
+constexpr int kSmallSegmentDefault = 256;
 constexpr int kTile = 2048;
 
 struct HBox {
@@ -745,7 +745,27 @@ __host__ __device__ inline int sah_bucket(float centroid, float cmn, float cmx) 
 struct SahChoice {
     int best, mid, split;
 };
-__host__ __device__ inline SahChoice sah_choose(const int *count, const HBox *bb, const HBox &bounds, int n,
+// bucket bounds arrive as 6 order-preserving keys per bucket (min xyz, max xyz), exactly as the
+// atomics left them, in LDS (wavefront subtrees) or host memory (breadth-first phase)
+__host__ __device__ inline float sah_key_to_float(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+__host__ __device__ inline HBox sah_bucket_box(const unsigned *keys, int b) {
+    HBox r;
+    for (int k = 0; k < 3; ++k) {
+        r.mn[k] = sah_key_to_float(keys[6 * b + k]);
+        r.mx[k] = sah_key_to_float(keys[6 * b + 3 + k]);
+    }
+    return r;
+}
+__host__ __device__ inline SahChoice sah_choose(const int *count, const unsigned *keys, const HBox &bounds, int n,
                                                 int maxPrims) {
     constexpr int nSplits = kSahBuckets - 1;
     float costs[nSplits];
@@ -754,7 +774,7 @@ __host__ __device__ inline SahChoice sah_choose(const int *count, const HBox *bb
     HBox bbelow;
     hb_init(bbelow);
     for (int i = 0; i < nSplits; ++i) {
-        hb_add(bbelow, bb[i]);
+        hb_add(bbelow, sah_bucket_box(keys, i));
         below += count[i];
         costs[i] += below * hb_area(bbelow);
     }
@@ -762,7 +782,7 @@ __host__ __device__ inline SahChoice sah_choose(const int *count, const HBox *bb
     HBox babove;
     hb_init(babove);
     for (int i = nSplits; i >= 1; --i) {
-        hb_add(babove, bb[i]);
+        hb_add(babove, sah_bucket_box(keys, i));
         above += count[i];
         costs[i - 1] += above * hb_area(babove);
     }
@@ -914,6 +934,54 @@ struct SmallSeg {
 };
 constexpr int kSubtreeStack = 64;
 
+// sah_choose for a wavefront: lane i < 11 prices split i (the same additions in the same order as
+// the sequential loops: buckets 0..i ascending for the part below, 11..i+1 descending for the part
+// above, cost = (0 + below) + above), then every lane scans the 11 costs in order, first minimum wins.
+__device__ __forceinline__ SahChoice sah_choose_wave(int lane, const int *count, const unsigned *keys,
+                                                     const HBox &bounds, int n, int maxPrims) {
+    float cost = __builtin_inff();
+    if (lane < kSahBuckets - 1) {
+        HBox acc;
+        hb_init(acc);
+        int cnt = 0;
+#pragma unroll 1
+        for (int q = 0; q <= lane; ++q) {
+            hb_add(acc, sah_bucket_box(keys, q));
+            cnt += count[q];
+        }
+        float c = 0;
+        c += cnt * hb_area(acc);
+        hb_init(acc);
+        cnt = 0;
+#pragma unroll 1
+        for (int q = kSahBuckets - 1; q > lane; --q) {
+            hb_add(acc, sah_bucket_box(keys, q));
+            cnt += count[q];
+        }
+        c += cnt * hb_area(acc);
+        cost = c;
+    }
+    int best = -1;
+    float minCost = __builtin_inff();
+#pragma unroll 1
+    for (int i = 0; i < kSahBuckets - 1; ++i) {
+        const float c = __shfl(cost, i);
+        if (c < minCost) {
+            minCost = c;
+            best = i;
+        }
+    }
+    const float leafCost = (float)n;
+    minCost = 1.f / 2.f + minCost / hb_area(bounds);
+    SahChoice ch;
+    ch.best = best;
+    ch.split = (n > maxPrims || minCost < leafCost) ? 1 : 0;
+    ch.mid = 0;
+#pragma unroll 1
+    for (int i = 0; i <= best; ++i) ch.mid += count[i];
+    return ch;
+}
+
 __global__ __launch_bounds__(64) void k_sah_subtrees(const SmallSeg *__restrict__ segs, int nSegs, int maxPrims,
                                                      const Box6 *__restrict__ pb, int *perm, int *lfPos, int *rtPos,
                                                      nnbvh_linear_node *pool, int *segCount, int *segDepth,
@@ -921,6 +989,7 @@ __global__ __launch_bounds__(64) void k_sah_subtrees(const SmallSeg *__restrict_
     __shared__ int stStart[kSubtreeStack], stN[kSubtreeStack], stParent[kSubtreeStack], stDepth[kSubtreeStack];
     __shared__ unsigned bkeys[kSahBuckets * 6];
     __shared__ int bcount[kSahBuckets];
+    __shared__ int lpos[64], rpos[64];
     const int s = blockIdx.x;
     if (s >= nSegs) return;
     const int lane = threadIdx.x;
@@ -930,13 +999,30 @@ __global__ __launch_bounds__(64) void k_sah_subtrees(const SmallSeg *__restrict_
     int start = sg.start, n = sg.n, depth = 0;
     for (;;) {
         const int me = idx++;
+        // A node of at most 64 primitives lives in registers (one primitive per lane) for all of its
+        // passes; larger ones loop over their range.
+        const bool small = n <= 64;
+        const bool mine = lane < n;
+        int myIdx = -1;
+        Box6 myBox;
+        box_init(myBox);
+        if (mine) {
+            myIdx = perm[start + lane];
+            myBox = pb[myIdx];
+        }
         // bounds and centroid bounds of the node (values)
         float v[12];
         for (int k = 0; k < 3; ++k) {
             v[k] = v[6 + k] = 3.402823466e+38f;
             v[3 + k] = v[9 + k] = -3.402823466e+38f;
         }
-        for (int j = lane; j < n; j += 64) {
+        if (mine)
+            for (int k = 0; k < 3; ++k) {
+                v[k] = myBox.mn[k];
+                v[3 + k] = myBox.mx[k];
+                v[6 + k] = v[9 + k] = .5f * myBox.mn[k] + .5f * myBox.mx[k];
+            }
+        for (int j = lane + 64; j < n; j += 64) {
             const Box6 b = pb[perm[start + j]];
             for (int k = 0; k < 3; ++k) {
                 v[k] = fminf(v[k], b.mn[k]);
@@ -966,22 +1052,28 @@ __global__ __launch_bounds__(64) void k_sah_subtrees(const SmallSeg *__restrict_
             if (cb.mx[dim] == cb.mn[dim]) leaf = true;  // :243
         }
         if (!leaf) {
+            const float cmn = cb.mn[dim], cmx = cb.mx[dim];
             if (n <= 2) {  // :289-296: nth_element of two = put the smaller centroid first
-                if (lane == 0) {
-                    const int i0 = perm[start], i1 = perm[start + 1];
-                    if (centroid_of(pb[i1], dim) < centroid_of(pb[i0], dim)) {
-                        perm[start] = i1;
-                        perm[start + 1] = i0;
-                    }
-                }
+                const float c0 = __shfl(centroid_of(myBox, dim), 0), c1 = __shfl(centroid_of(myBox, dim), 1);
+                if (c1 < c0 && lane < 2) perm[start + (1 - lane)] = myIdx;
                 mid = n / 2;
+                __threadfence_block();
             } else {
                 if (lane < kSahBuckets) bcount[lane] = 0;
                 for (int q = lane; q < kSahBuckets * 6; q += 64) bkeys[q] = (q % 6) < 3 ? 0xffffffffu : 0u;
                 __syncthreads();
-                for (int j = lane; j < n; j += 64) {
+                int myBucket = 0;
+                if (mine) {
+                    myBucket = sah_bucket(centroid_of(myBox, dim), cmn, cmx);
+                    atomicAdd(&bcount[myBucket], 1);
+                    for (int k = 0; k < 3; ++k) {
+                        atomicMin(&bkeys[myBucket * 6 + k], f2key(myBox.mn[k]));
+                        atomicMax(&bkeys[myBucket * 6 + 3 + k], f2key(myBox.mx[k]));
+                    }
+                }
+                for (int j = lane + 64; j < n; j += 64) {
                     const Box6 b = pb[perm[start + j]];
-                    const int bk = sah_bucket(centroid_of(b, dim), cb.mn[dim], cb.mx[dim]);
+                    const int bk = sah_bucket(centroid_of(b, dim), cmn, cmx);
                     atomicAdd(&bcount[bk], 1);
                     for (int k = 0; k < 3; ++k) {
                         atomicMin(&bkeys[bk * 6 + k], f2key(b.mn[k]));
@@ -989,29 +1081,37 @@ __global__ __launch_bounds__(64) void k_sah_subtrees(const SmallSeg *__restrict_
                     }
                 }
                 __syncthreads();
-                int count[kSahBuckets];
-                HBox bb[kSahBuckets];
-                for (int b = 0; b < kSahBuckets; ++b) {
-                    count[b] = bcount[b];
-                    for (int k = 0; k < 3; ++k) {
-                        bb[b].mn[k] = key2f(bkeys[b * 6 + k]);
-                        bb[b].mx[k] = key2f(bkeys[b * 6 + 3 + k]);
-                    }
-                }
-                const SahChoice ch = sah_choose(count, bb, bounds, n, maxPrims);
+                const SahChoice ch = sah_choose_wave(lane, bcount, bkeys, bounds, n, maxPrims);
                 __syncthreads();  // everyone has read the buckets before the next node clears them
                 if (!ch.split) {
                     leaf = true;
+                } else if (small) {
+                    best = ch.best;
+                    mid = ch.mid;
+                    // std::partition(bucket <= best) by ranks, in registers: the k-th offender of the
+                    // left part (from the left) trades places with the k-th of the right part from the right
+                    const bool pred = myBucket <= best;
+                    const bool leftOff = mine && lane < mid && !pred, rightOff = mine && lane >= mid && pred;
+                    const unsigned long long mL = __ballot(leftOff), mR = __ballot(rightOff);
+                    const int kL = __popcll(mL & ((1ull << lane) - 1ull));
+                    const int kR = lane == 63 ? 0 : __popcll(mR >> (lane + 1));
+                    if (leftOff) lpos[kL] = lane;
+                    if (rightOff) rpos[kR] = lane;
+                    __syncthreads();
+                    if (leftOff) perm[start + rpos[kL]] = myIdx;
+                    if (rightOff) perm[start + lpos[kR]] = myIdx;
+                    if (__popcll(mL) != __popcll(mR) && lane == 0) *err = 100;  // cannot happen
+                    __syncthreads();
+                    __threadfence_block();
                 } else {
                     best = ch.best;
                     mid = ch.mid;
-                    // std::partition(bucket <= best) by ranks: offenders of the left part from the left ...
+                    // the same by ranks through scratch: offenders of the left part from the left ...
                     int nl = 0;
                     for (int base = 0; base < mid; base += 64) {
                         const int j = base + lane;
                         bool f = false;
-                        if (j < mid)
-                            f = sah_bucket(centroid_of(pb[perm[start + j]], dim), cb.mn[dim], cb.mx[dim]) > best;
+                        if (j < mid) f = sah_bucket(centroid_of(pb[perm[start + j]], dim), cmn, cmx) > best;
                         const unsigned long long mask = __ballot(f);
                         if (f) lfPos[start + nl + __popcll(mask & ((1ull << lane) - 1ull))] = start + j;
                         nl += __popcll(mask);
@@ -1021,8 +1121,7 @@ __global__ __launch_bounds__(64) void k_sah_subtrees(const SmallSeg *__restrict_
                     for (int top = n; top > mid; top -= 64) {
                         const int j = top - 1 - lane;
                         bool f = false;
-                        if (j >= mid)
-                            f = sah_bucket(centroid_of(pb[perm[start + j]], dim), cb.mn[dim], cb.mx[dim]) <= best;
+                        if (j >= mid) f = sah_bucket(centroid_of(pb[perm[start + j]], dim), cmn, cmx) <= best;
                         const unsigned long long mask = __ballot(f);
                         if (f) rtPos[start + nr + __popcll(mask & ((1ull << lane) - 1ull))] = start + j;
                         nr += __popcll(mask);
@@ -1073,11 +1172,15 @@ __global__ __launch_bounds__(64) void k_sah_subtrees(const SmallSeg *__restrict_
         }
         // leaf (:222-236 / :243-253 / :365-369): bounds = in-order fold over its primitives
         {
-            const int chunk = (n + 63) / 64;
-            const int lo = lane * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
             Box6 b;
-            box_init(b);
-            for (int j = lo; j < hi; ++j) box_add(b, pb[perm[start + j]]);
+            if (small) {
+                b = myBox;  // one primitive per lane, already in order (empty lanes hold the empty box)
+            } else {
+                const int chunk = (n + 63) / 64;
+                const int lo = lane * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+                box_init(b);
+                for (int j = lo; j < hi; ++j) box_add(b, pb[perm[start + j]]);
+            }
             for (int off = 1; off < 64; off <<= 1) {
                 Box6 o;
                 for (int k = 0; k < 3; ++k) {
@@ -1319,13 +1422,8 @@ bool gpu_sah(const nnbvh_prim *prims, int n, const float *verts, int n_verts, co
         for (int s = 0; s < nSeg; ++s) {
             HostNode &hn = hostNodes[(size_t)level[s].host];
             if (!delegate[s]) {
-                HBox bb[kSahBuckets];
-                for (int b = 0; b < kSahBuckets; ++b)
-                    for (int k = 0; k < 3; ++k) {
-                        bb[b].mn[k] = key_to_float(bkeys[(kSahBuckets * (size_t)s + b) * 6 + k]);
-                        bb[b].mx[k] = key_to_float(bkeys[(kSahBuckets * (size_t)s + b) * 6 + 3 + k]);
-                    }
-                const SahChoice ch = sah_choose(&bcounts[kSahBuckets * (size_t)s], bb, segBounds[s], level[s].n, maxPrims);
+                const SahChoice ch = sah_choose(&bcounts[kSahBuckets * (size_t)s], &bkeys[kSahBuckets * 6 * (size_t)s],
+                                                segBounds[s], level[s].n, maxPrims);
                 if (!ch.split || ch.mid <= 0 || ch.mid >= level[s].n) delegate[s] = 1;
                 else {
                     infos[s].best = ch.best;
