@@ -343,3 +343,50 @@ def test_maximum_depth_and_maximum_leaf_size():
     eocc, evis, etst = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, 16)
     assert (occ == eocc).all() and (tst == etst).all()
     agg.close()
+
+
+def test_device_entry_points_are_hip_graph_capturable():
+    """The *_device entry points only enqueue work on the caller's stream (a memset and kernels)
+    once that stream's workspace exists, so a wavefront iteration can be captured in a hipGraph and
+    replayed; results equal the eager ones."""
+    import torch
+    verts, prims = ss.random_soup(3000, 300, 41)
+    tree = build_tree(prims, verts)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+    rays = scene.random_rays(50000, verts.min(0) - 2, verts.max(0) + 2, 42)
+    shadow = rays.copy()
+    shadow["tmax"] = np.float32(7.5)
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1)).to(dev)  # noqa: E731
+    d_rays, d_shadow = up(rays), up(shadow)
+    d_hits = torch.zeros(len(rays) * 32, dtype=torch.uint8, device=dev)
+    d_occ = torch.zeros(len(rays), dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()  # the buffers' zero-fills ran on the default stream
+
+    def step(stream):
+        agg.intersect_device(d_rays.data_ptr(), d_hits.data_ptr(), len(rays), stream)
+        agg.intersect_p_device(d_shadow.data_ptr(), d_occ.data_ptr(), len(rays), stream=stream)
+
+    with torch.cuda.stream(side):
+        step(side.cuda_stream)  # warm-up: creates this stream's workspace (allocation is not capturable)
+    torch.cuda.synchronize()
+    eager_hits, eager_occ = d_hits.clone(), d_occ.clone()
+    d_hits.zero_()
+    d_occ.zero_()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        step(side.cuda_stream)
+    torch.cuda.synchronize()
+    assert not d_hits.any(), "capture must not execute the work"
+    for _ in range(3):
+        d_hits.zero_()
+        d_occ.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(d_hits, eager_hits) and torch.equal(d_occ, eager_occ)
+    exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, nthreads=8)
+    assert_hits_equal(d_hits.cpu().numpy().view(exp.dtype), exp, "graph replay")
+    agg.close()
