@@ -737,7 +737,8 @@ __host__ __device__ inline int sah_bucket(float centroid, float cmn, float cmx) 
     float o = centroid - cmn;
     if (cmx > cmn) o /= cmx - cmn;
     int b = kSahBuckets * o;
-    if (b == kSahBuckets) b = kSahBuckets - 1;
+    if (b >= kSahBuckets) b = kSahBuckets - 1;  // == 12 for the largest centroid (:316); beyond only for
+    if (b < 0) b = 0;                           // non-finite input, which must not index out of range
     return b;
 }
 // the decision of :319-371 from the node's buckets: best split, how many primitives go left,
