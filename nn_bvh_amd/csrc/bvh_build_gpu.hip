@@ -1033,9 +1033,17 @@ __global__ __launch_bounds__(64) void k_sah_subtrees(const SmallSeg *__restrict_
                 v[9 + k] = fmaxf(v[9 + k], c);
             }
         }
+        // butterfly over the lanes that can hold data (lanes >= n hold the neutral element); most
+        // nodes are tiny, so most of the 6 steps are skipped
+        int span = 64;
+        if (n < 64) {
+            span = 1;
+            while (span < n) span <<= 1;
+        }
         for (int q = 0; q < 12; ++q) {
             const bool isMin = (q % 6) < 3;
             for (int off = 32; off >= 1; off >>= 1) {
+                if (off >= span) continue;
                 const float o = __shfl_xor(v[q], off);
                 v[q] = isMin ? fminf(v[q], o) : fmaxf(v[q], o);
             }
@@ -1182,7 +1190,7 @@ __global__ __launch_bounds__(64) void k_sah_subtrees(const SmallSeg *__restrict_
                 box_init(b);
                 for (int j = lo; j < hi; ++j) box_add(b, pb[perm[start + j]]);
             }
-            for (int off = 1; off < 64; off <<= 1) {
+            for (int off = 1; off < (small ? span : 64); off <<= 1) {
                 Box6 o;
                 for (int k = 0; k < 3; ++k) {
                     o.mn[k] = __shfl_down(b.mn[k], off);

@@ -644,9 +644,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     p.intRepeat = s->int_repeat;
     p.hasHostPrims = s->has_host_prims;
     p.spill = w->spill;
-    if (!hip_ok(hipMemsetAsync(w->queue, 0, kMaxQueues * kQueueStrideWords * sizeof(unsigned),
-                               stream),
-                "hipMemsetAsync(queue)"))
+    if (!hip_ok(launch_zero_queue(w->queue, kMaxQueues * kQueueStrideWords, stream), "queue reset launch"))
         return NNBVH_ERR_DEVICE;
     // never launch more threads than there are rays to start with (tiny batches)
     int blocks = grid_blocks(s, mode);

@@ -34,6 +34,8 @@ struct TraceParams {
     uint2 *spill;           // [kMaxStack][grid threads] overflow of the LDS stack window
 };
 
+hipError_t launch_zero_queue(unsigned *queue, int words, hipStream_t stream);
+
 // occupancy != nullptr: do not launch, report resident blocks per CU of that kernel instance
 hipError_t launch_trace(int mode, const TraceParams &p, int window, int instanced, int blocks,
                         hipStream_t stream, int *occupancy);

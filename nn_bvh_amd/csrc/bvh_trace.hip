@@ -738,6 +738,16 @@ static hipError_t launch_mode(const TraceParams &p, int window, int instanced, i
     }
 }
 
+// The queue heads are cleared by a (tiny) kernel rather than hipMemsetAsync: as a kernel node the
+// clear keeps its place between the launches of a captured hipGraph.
+__global__ void zero_queue_kernel(unsigned *queue, int words) {
+    for (int i = threadIdx.x; i < words; i += blockDim.x) queue[i] = 0u;
+}
+hipError_t launch_zero_queue(unsigned *queue, int words, hipStream_t stream) {
+    hipLaunchKernelGGL(zero_queue_kernel, dim3(1), dim3(256), 0, stream, queue, words);
+    return hipGetLastError();
+}
+
 // occupancy != nullptr: no launch, only report resident blocks per CU for that instance
 hipError_t launch_trace(int mode, const TraceParams &p, int window, int instanced, int blocks,
                         hipStream_t stream, int *occupancy) {
