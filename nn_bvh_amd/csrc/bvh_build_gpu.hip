@@ -760,10 +760,13 @@ __host__ __device__ inline float sah_key_to_float(unsigned k) {
 }
 __host__ __device__ inline HBox sah_bucket_box(const unsigned *keys, int b) {
     HBox r;
-    for (int k = 0; k < 3; ++k) {
-        r.mn[k] = sah_key_to_float(keys[6 * b + k]);
-        r.mx[k] = sah_key_to_float(keys[6 * b + 3 + k]);
-    }
+    const unsigned *k6 = keys + 6 * b;
+    r.mn[0] = sah_key_to_float(k6[0]);
+    r.mn[1] = sah_key_to_float(k6[1]);
+    r.mn[2] = sah_key_to_float(k6[2]);
+    r.mx[0] = sah_key_to_float(k6[3]);
+    r.mx[1] = sah_key_to_float(k6[4]);
+    r.mx[2] = sah_key_to_float(k6[5]);
     return r;
 }
 __host__ __device__ inline SahChoice sah_choose(const int *count, const unsigned *keys, const HBox &bounds, int n,
@@ -774,6 +777,7 @@ __host__ __device__ inline SahChoice sah_choose(const int *count, const unsigned
     int below = 0;
     HBox bbelow;
     hb_init(bbelow);
+#pragma unroll 1
     for (int i = 0; i < nSplits; ++i) {
         hb_add(bbelow, sah_bucket_box(keys, i));
         below += count[i];
@@ -782,6 +786,7 @@ __host__ __device__ inline SahChoice sah_choose(const int *count, const unsigned
     int above = 0;
     HBox babove;
     hb_init(babove);
+#pragma unroll 1
     for (int i = nSplits; i >= 1; --i) {
         hb_add(babove, sah_bucket_box(keys, i));
         above += count[i];
@@ -789,6 +794,7 @@ __host__ __device__ inline SahChoice sah_choose(const int *count, const unsigned
     }
     int best = -1;
     float minCost = __builtin_inff();
+#pragma unroll 1
     for (int i = 0; i < nSplits; ++i)
         if (costs[i] < minCost) {
             minCost = costs[i];
@@ -927,6 +933,70 @@ __global__ __launch_bounds__(kB) void k_seg_swap(const Tile *__restrict__ tiles,
             perm[b] = va;
         }
     }
+}
+
+// per-node decisions on the device (one thread per big node of the level): nothing but the final
+// {dim, mid} verdicts crosses PCIe
+struct SegStart {
+    int start, n;
+};
+__global__ __launch_bounds__(kB) void k_seg_init(int nSeg, unsigned *__restrict__ segAcc, unsigned *__restrict__ segKeys,
+                                                 int *__restrict__ segCounts) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i < 12 * nSeg) segAcc[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+    if (i < kSahBuckets * 6 * nSeg) segKeys[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+    if (i < kSahBuckets * nSeg) segCounts[i] = 0;
+}
+// :221, :241-253: flat bounds or coincident centroids -> no split (the node is handed to a wavefront,
+// which makes the leaf); otherwise the split axis and the centroid range along it
+__global__ __launch_bounds__(kB) void k_seg_prepare(const SegStart *__restrict__ segs, int nSeg,
+                                                    const unsigned *__restrict__ segAcc, SegInfo *__restrict__ info,
+                                                    HBox *__restrict__ segBounds) {
+    const int s = blockIdx.x * kB + threadIdx.x;
+    if (s >= nSeg) return;
+    HBox b, cb;
+    for (int k = 0; k < 3; ++k) {
+        b.mn[k] = sah_key_to_float(segAcc[12 * s + k]);
+        b.mx[k] = sah_key_to_float(segAcc[12 * s + 3 + k]);
+        cb.mn[k] = sah_key_to_float(segAcc[12 * s + 6 + k]);
+        cb.mx[k] = sah_key_to_float(segAcc[12 * s + 9 + k]);
+    }
+    const int dim = hb_maxdim(cb);
+    const bool noSplit = hb_area(b) == 0 || cb.mx[dim] == cb.mn[dim];
+    SegInfo si;
+    si.start = segs[s].start;
+    si.n = segs[s].n;
+    si.mid = 0;
+    si.dim = dim;
+    si.best = noSplit ? -2 : -1;  // -2: decided, no split; -1: buckets wanted
+    si.cmn = cb.mn[dim];
+    si.cmx = cb.mx[dim];
+    info[s] = si;
+    segBounds[s] = b;
+}
+__global__ __launch_bounds__(kB) void k_seg_choose(int nSeg, int maxPrims, const int *__restrict__ segCounts,
+                                                   const unsigned *__restrict__ segKeys,
+                                                   const HBox *__restrict__ segBounds, SegInfo *info,
+                                                   int2 *__restrict__ verdict) {
+    const int s = blockIdx.x * kB + threadIdx.x;
+    if (s >= nSeg) return;
+    SegInfo si = info[s];
+    int mid = 0;
+    if (si.best != -2) {
+        const SahChoice ch = sah_choose(segCounts + kSahBuckets * s, segKeys + kSahBuckets * 6 * s, segBounds[s], si.n,
+                                        maxPrims);
+        if (ch.split && ch.mid > 0 && ch.mid < si.n) {
+            si.best = ch.best;
+            mid = ch.mid;
+        } else {
+            si.best = -1;
+        }
+    } else {
+        si.best = -1;
+    }
+    si.mid = mid;  // mid == 0: no split; the flags kernel then leaves the node's primitives in place
+    info[s] = si;
+    verdict[s] = make_int2(si.dim, mid);
 }
 
 // ---- phase B: one wavefront builds one subtree ----------------------------------------------------------
@@ -1360,20 +1430,25 @@ bool gpu_sah(const nnbvh_prim *prims, int n, const float *verts, int n_verts, co
     };
     rootRef = make_child(0, n, level);
     std::vector<Tile> tiles;
-    std::vector<SegInfo> infos;
-    std::vector<unsigned> acc, bkeys;
-    std::vector<int> bcounts;
     Tile *dTiles = nullptr;
     SegInfo *dInfo = nullptr;
     unsigned *dAcc = nullptr, *dBKeys = nullptr;
     int *dBCounts = nullptr;
     size_t capTiles = 0, capSegs = 0;
+    std::vector<SegStart> segStarts;
+    std::vector<int2> verdicts;
+    SegStart *dSegStart = nullptr;
+    HBox *dSegBounds = nullptr;
+    int2 *dVerdict = nullptr;
     while (!level.empty()) {
         const int nSeg = (int)level.size();
         tiles.clear();
-        for (int s = 0; s < nSeg; ++s)
+        segStarts.resize((size_t)nSeg);
+        for (int s = 0; s < nSeg; ++s) {
+            segStarts[(size_t)s] = SegStart{level[s].start, level[s].n};
             for (int off = 0; off < level[s].n; off += kTile)
                 tiles.push_back(Tile{s, level[s].start + off, std::min(kTile, level[s].n - off)});
+        }
         if (tiles.size() > capTiles) {
             capTiles = tiles.size() * 2;
             dTiles = mem.get<Tile>(capTiles);
@@ -1384,72 +1459,22 @@ bool gpu_sah(const nnbvh_prim *prims, int n, const float *verts, int n_verts, co
             dAcc = mem.get<unsigned>(12 * capSegs);
             dBKeys = mem.get<unsigned>(kSahBuckets * 6 * capSegs);
             dBCounts = mem.get<int>(kSahBuckets * capSegs);
+            dSegStart = mem.get<SegStart>(capSegs);
+            dSegBounds = mem.get<HBox>(capSegs);
+            dVerdict = mem.get<int2>(capSegs);
         }
         if (!mem.ok) return false;
         const int nTiles = (int)tiles.size();
         GB_CHECK(hipMemcpyAsync(dTiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, stream), "copy tiles");
-        acc.assign(12 * (size_t)nSeg, 0u);
-        for (int s = 0; s < nSeg; ++s)
-            for (int q = 0; q < 12; ++q) acc[12 * (size_t)s + q] = (q % 6) < 3 ? 0xffffffffu : 0u;
-        GB_CHECK(hipMemcpyAsync(dAcc, acc.data(), acc.size() * sizeof(unsigned), hipMemcpyHostToDevice, stream), "init accumulators");
+        GB_CHECK(hipMemcpyAsync(dSegStart, segStarts.data(), segStarts.size() * sizeof(SegStart), hipMemcpyHostToDevice, stream),
+                 "copy nodes");
+        hipLaunchKernelGGL(k_seg_init, dim3(grid_all((long)kSahBuckets * 6 * nSeg)), dim3(kB), 0, stream, nSeg, dAcc, dBKeys,
+                           dBCounts);
         hipLaunchKernelGGL(k_seg_reduce, dim3(nTiles), dim3(kB), 0, stream, dTiles, dPb, dPerm, dAcc);
-        GB_CHECK(hipMemcpyAsync(acc.data(), dAcc, acc.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream), "read accumulators");
-        GB_CHECK(hipStreamSynchronize(stream), "sync (bounds)");
-        auto key_to_float = [](unsigned k) {
-            const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-            float f;
-            std::memcpy(&f, &u, 4);
-            return f;
-        };
-        infos.assign((size_t)nSeg, SegInfo{});
-        std::vector<HBox> segBounds((size_t)nSeg);
-        std::vector<char> delegate((size_t)nSeg, 0);  // the wavefront builder will make the leaf
-        for (int s = 0; s < nSeg; ++s) {
-            HBox b, cb;
-            for (int k = 0; k < 3; ++k) {
-                b.mn[k] = key_to_float(acc[12 * (size_t)s + k]);
-                b.mx[k] = key_to_float(acc[12 * (size_t)s + 3 + k]);
-                cb.mn[k] = key_to_float(acc[12 * (size_t)s + 6 + k]);
-                cb.mx[k] = key_to_float(acc[12 * (size_t)s + 9 + k]);
-            }
-            segBounds[s] = b;
-            const int dim = hb_maxdim(cb);
-            if (hb_area(b) == 0 || cb.mx[dim] == cb.mn[dim]) delegate[s] = 1;
-            infos[s] = SegInfo{level[s].start, level[s].n, 0, dim, 0, cb.mn[dim], cb.mx[dim]};
-        }
-        GB_CHECK(hipMemcpyAsync(dInfo, infos.data(), infos.size() * sizeof(SegInfo), hipMemcpyHostToDevice, stream), "copy node info");
-        bkeys.assign(kSahBuckets * 6 * (size_t)nSeg, 0u);
-        for (size_t q = 0; q < bkeys.size(); ++q) bkeys[q] = (q % 6) < 3 ? 0xffffffffu : 0u;
-        bcounts.assign(kSahBuckets * (size_t)nSeg, 0);
-        GB_CHECK(hipMemcpyAsync(dBKeys, bkeys.data(), bkeys.size() * sizeof(unsigned), hipMemcpyHostToDevice, stream), "init buckets");
-        GB_CHECK(hipMemcpyAsync(dBCounts, bcounts.data(), bcounts.size() * sizeof(int), hipMemcpyHostToDevice, stream), "init buckets");
+        hipLaunchKernelGGL(k_seg_prepare, dim3(grid_all(nSeg)), dim3(kB), 0, stream, dSegStart, nSeg, dAcc, dInfo, dSegBounds);
         hipLaunchKernelGGL(k_seg_buckets, dim3(nTiles), dim3(kB), 0, stream, dTiles, dInfo, dPb, dPerm, dBKeys, dBCounts);
-        GB_CHECK(hipMemcpyAsync(bkeys.data(), dBKeys, bkeys.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream), "read buckets");
-        GB_CHECK(hipMemcpyAsync(bcounts.data(), dBCounts, bcounts.size() * sizeof(int), hipMemcpyDeviceToHost, stream), "read buckets");
-        GB_CHECK(hipStreamSynchronize(stream), "sync (buckets)");
-        std::vector<Big> next;
-        for (int s = 0; s < nSeg; ++s) {
-            HostNode &hn = hostNodes[(size_t)level[s].host];
-            if (!delegate[s]) {
-                const SahChoice ch = sah_choose(&bcounts[kSahBuckets * (size_t)s], &bkeys[kSahBuckets * 6 * (size_t)s],
-                                                segBounds[s], level[s].n, maxPrims);
-                if (!ch.split || ch.mid <= 0 || ch.mid >= level[s].n) delegate[s] = 1;
-                else {
-                    infos[s].best = ch.best;
-                    infos[s].mid = ch.mid;
-                }
-            }
-            if (delegate[s]) {
-                // a big node that does not split (coincident centroids / flat bounds): mark it; it
-                // becomes a subtree handled by the wavefront builder, which reaches the same verdict
-                infos[s].mid = 0;
-                infos[s].best = -1;
-                hn.axis = -1;
-                continue;
-            }
-            hn.axis = infos[s].dim;
-        }
-        GB_CHECK(hipMemcpyAsync(dInfo, infos.data(), infos.size() * sizeof(SegInfo), hipMemcpyHostToDevice, stream), "copy splits");
+        hipLaunchKernelGGL(k_seg_choose, dim3(grid_all(nSeg)), dim3(kB), 0, stream, nSeg, maxPrims, dBCounts, dBKeys, dSegBounds,
+                           dInfo, dVerdict);
         GB_CHECK(hipMemsetAsync(dLfFlag, 0, ((size_t)n + 1) * sizeof(int), stream), "memset");
         GB_CHECK(hipMemsetAsync(dRtFlag, 0, ((size_t)n + 1) * sizeof(int), stream), "memset");
         hipLaunchKernelGGL(k_seg_flags, dim3(nTiles), dim3(kB), 0, stream, dTiles, dInfo, dPb, dPerm, dLfFlag, dRtFlag);
@@ -1458,22 +1483,28 @@ bool gpu_sah(const nnbvh_prim *prims, int n, const float *verts, int n_verts, co
         hipLaunchKernelGGL(k_seg_positions, dim3(nTiles), dim3(kB), 0, stream, dTiles, dInfo, dLfFlag, dLfScan, dRtFlag,
                            dRtScan, dLfPos, dRtPos);
         hipLaunchKernelGGL(k_seg_swap, dim3(nTiles), dim3(kB), 0, stream, dTiles, dInfo, dLfScan, dLfPos, dRtPos, dPerm);
+        verdicts.resize((size_t)nSeg);
+        GB_CHECK(hipMemcpyAsync(verdicts.data(), dVerdict, (size_t)nSeg * sizeof(int2), hipMemcpyDeviceToHost, stream), "read verdicts");
+        GB_CHECK(hipStreamSynchronize(stream), "sync (level)");
+        std::vector<Big> next;
         for (int s = 0; s < nSeg; ++s) {
-            if (delegate[s]) continue;
-            HostNode &hn = hostNodes[(size_t)level[s].host];
-            const int c0 = make_child(level[s].start, infos[s].mid, next);
-            const int c1 = make_child(level[s].start + infos[s].mid, level[s].n - infos[s].mid, next);
-            hostNodes[(size_t)level[s].host].child[0] = c0;  // (hn may dangle after push_back)
-            hostNodes[(size_t)level[s].host].child[1] = c1;
-            (void)hn;
-        }
-        // delegated big nodes: replace the host node by a subtree reference in its parent later
-        for (int s = 0; s < nSeg; ++s)
-            if (delegate[s]) {
+            const int dim = verdicts[(size_t)s].x, mid = verdicts[(size_t)s].y;
+            const int host = level[s].host;
+            if (mid <= 0) {
+                // a big node that does not split (coincident centroids / flat bounds): it becomes a
+                // subtree for the wavefront builder, which reaches the same verdict and makes the leaf
                 smallSegs.push_back(SmallSeg{level[s].start, level[s].n, 0});
-                hostNodes[(size_t)level[s].host].child[0] = ~((int)smallSegs.size() - 1);
-                hostNodes[(size_t)level[s].host].child[1] = 0;
+                hostNodes[(size_t)host].axis = -1;
+                hostNodes[(size_t)host].child[0] = ~((int)smallSegs.size() - 1);
+                hostNodes[(size_t)host].child[1] = 0;
+                continue;
             }
+            const int c0 = make_child(level[s].start, mid, next);
+            const int c1 = make_child(level[s].start + mid, level[s].n - mid, next);
+            hostNodes[(size_t)host].axis = dim;  // (index again: make_child may have grown the vector)
+            hostNodes[(size_t)host].child[0] = c0;
+            hostNodes[(size_t)host].child[1] = c1;
+        }
         level.swap(next);
     }
     // k_seg_flags marks delegated nodes' primitives with pred = (bucket <= -1) = false and mid = 0:
