@@ -283,7 +283,7 @@ def main():
         # (Triangle::InteractionFromIntersection, which the reference's Intersect runs per hit)
         from nn_bvh_amd.interaction import ShadingMesh
         smesh = ShadingMesh(verts, tris, device=local_rank)
-        d_intr = torch.empty(n_primary * 160, dtype=torch.uint8, device=cdev)
+        d_intr = torch.empty(n_primary * 192, dtype=torch.uint8, device=cdev)
 
         def step_wavefront_intr():
             step_wavefront()

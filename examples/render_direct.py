@@ -76,7 +76,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         hits = wf.IntersectClosest(n, rq, escaped=escaped, basic_eval_material=material)
-        intr = torch.empty((n, 40), dtype=torch.float32, device=dev)
+        intr = torch.empty((n, 48), dtype=torch.float32, device=dev)  # nnbvh_interaction = 192 B
         smesh.interactions_device(hits.data_ptr(), n, intr.data_ptr(), ray_queue=rq,
                                   stream=torch.cuda.current_stream(dev).cuda_stream)
         torch.cuda.synchronize()

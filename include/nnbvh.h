@@ -267,8 +267,8 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
                                      const float *d_r_l, const int32_t *d_pixel_index, float *d_L,
                                      int64_t n_pixels, uint8_t *d_occluded, void *stream);
 
-/* ---- hit record -> SurfaceInteraction: Triangle::InteractionFromIntersection -----------------
- * (shapes.h:884-1010, run by Triangle::Intersect, shapes.cpp:302-334, on every reported hit; with
+/* ---- hit record -> SurfaceInteraction: Triangle:: / BilinearPatch::InteractionFromIntersection --
+ * (shapes.h:884-1010 and 1396-1489, run by the shapes' Intersect on every reported hit; with
  * the SurfaceInteraction constructor and SetShadingGeometry, interaction.h:32-33, 164-214).  A
  * device post-pass over a batch of hit records; bit-identical to the reference function.
  * The mesh data are TriangleMesh's (util/mesh.h:24-72) flattened over all meshes of the scene, in
@@ -279,22 +279,27 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
 #define NNBVH_TRI_HAS_N 4
 #define NNBVH_TRI_HAS_S 8
 typedef struct nnbvh_shading_mesh nnbvh_shading_mesh;
-/* tri_vertices: 3 vertex indices per triangle, triangle k being the primitive whose nnbvh_prim.id
- * is k (v[0] < 0: not a triangle).  normals / tangents: 3 floats per vertex, uvs: 2, face_indices:
- * 1 int per triangle; each nullable.  tri_flags: NNBVH_TRI_* per triangle; NULL = no flip and the
- * HAS_* bits follow from which arrays were given. */
+/* tri_vertices: 3 vertex indices per primitive, primitive k being the one whose nnbvh_prim.id is k
+ * (v[0] < 0: not a triangle).  patch_vertices (nullable): 4 per primitive, p00 p10 p01 p11
+ * (v[0] < 0: not a bilinear patch; BilinearPatchMesh, util/mesh.h:50-72).  normals / tangents: 3
+ * floats per vertex, uvs: 2, face_indices: 1 int per primitive; each nullable.  tri_flags:
+ * NNBVH_TRI_* per primitive; NULL = no flip and the HAS_* bits follow from which arrays were given. */
 nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
-                                              const int32_t *tri_vertices, int n_tris,
+                                              const int32_t *tri_vertices,
+                                              const int32_t *patch_vertices, int n_prims,
                                               const float *normals, const float *uvs,
                                               const float *tangents, const int32_t *face_indices,
                                               const uint8_t *tri_flags, int device);
 void nnbvh_shading_mesh_destroy(nnbvh_shading_mesh *m);
 
 #define NNBVH_INTERACTION_MISS 0
-#define NNBVH_INTERACTION_TRIANGLE 1 /* all fields valid; otherwise only prim and status are written */
-#define NNBVH_INTERACTION_HOST 2     /* hit on a bilinear patch, inside an instance or on a host
-                                        primitive: the caller finishes it on the host */
-typedef struct nnbvh_interaction {   /* 160 B */
+#define NNBVH_INTERACTION_TRIANGLE 1 /* all fields valid (Triangle::InteractionFromIntersection) */
+#define NNBVH_INTERACTION_HOST 2     /* hit inside an instance or on a host primitive (or on a primitive
+                                        the mesh has no vertices for): the caller finishes it on the
+                                        host; only prim and status are written, as for a miss */
+#define NNBVH_INTERACTION_PATCH 3    /* all fields valid (BilinearPatch::InteractionFromIntersection,
+                                        shapes.h:1396-1489) */
+typedef struct nnbvh_interaction {   /* 192 B */
     float pi_lo[3], pi_hi[3]; /* Point3fi pi = pHit +- gamma(7) sum|b_i p_i| (shapes.h:926-930) */
     float uv[2];
     float wo[3];              /* Normalize(-ray.d) */
@@ -303,9 +308,11 @@ typedef struct nnbvh_interaction {   /* 160 B */
     int32_t face_index;
     float dpdu[3], dpdv[3];
     float ns[3], dpdus[3], dpdvs[3], dndus[3], dndvs[3]; /* SurfaceInteraction::shading */
+    float dndu[3], dndv[3];   /* geometric normal derivatives (zero for triangles) */
+    float pad0;
     int32_t prim;             /* the hit record's primitive id, -1 = miss */
     int32_t status;           /* NNBVH_INTERACTION_* */
-    int32_t pad;
+    int32_t pad1[2];
 } nnbvh_interaction;
 /* One of d_rays (nnbvh_ray[max_items]) / ray_soa gives the rays the hits belong to (direction and
  * time are read).  n = min(max_items, *d_size) when d_size != NULL.  d_out: nnbvh_interaction

@@ -175,16 +175,17 @@ class HipBVHAggregate {
     nnbvh_scene *scene_ = nullptr;
 };
 
-// Triangle::InteractionFromIntersection (shapes.h:884-1010) for batches of hit records: the mesh
+// Triangle:: / BilinearPatch::InteractionFromIntersection (shapes.h:884-1010, 1396-1489) for batches of hit records: the mesh
 // side of a pbrt scene (TriangleMesh arrays flattened over all meshes) + the post-pass.
 class HipShadingMesh {
   public:
-    HipShadingMesh(const float *verts, int nVerts, const int32_t *triVertices, int nTris,
+    HipShadingMesh(const float *verts, int nVerts, const int32_t *triVertices, int nPrims,
                    const float *normals = nullptr, const float *uvs = nullptr,
                    const float *tangents = nullptr, const int32_t *faceIndices = nullptr,
-                   const uint8_t *triFlags = nullptr, int device = 0)
-        : mesh_(nnbvh_shading_mesh_create(verts, nVerts, triVertices, nTris, normals, uvs, tangents,
-                                          faceIndices, triFlags, device)) {
+                   const uint8_t *triFlags = nullptr, int device = 0,
+                   const int32_t *patchVertices = nullptr)
+        : mesh_(nnbvh_shading_mesh_create(verts, nVerts, triVertices, patchVertices, nPrims, normals,
+                                          uvs, tangents, faceIndices, triFlags, device)) {
         if (!mesh_) HipBVHAggregate::fatal("HipShadingMesh");
     }
     ~HipShadingMesh() { nnbvh_shading_mesh_destroy(mesh_); }

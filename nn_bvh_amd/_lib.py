@@ -30,10 +30,10 @@ CLASS_BASIC, CLASS_UNIVERSAL, CLASS_INTERFACE, CLASS_AREA_LIGHT = 0, 1, 2, 4
 INTERACTION_DTYPE = np.dtype([("pi_lo", "<f4", 3), ("pi_hi", "<f4", 3), ("uv", "<f4", 2), ("wo", "<f4", 3),
                               ("time", "<f4"), ("n", "<f4", 3), ("face_index", "<i4"), ("dpdu", "<f4", 3),
                               ("dpdv", "<f4", 3), ("ns", "<f4", 3), ("dpdus", "<f4", 3), ("dpdvs", "<f4", 3),
-                              ("dndus", "<f4", 3), ("dndvs", "<f4", 3), ("prim", "<i4"), ("status", "<i4"),
-                              ("pad", "<i4")])
+                              ("dndus", "<f4", 3), ("dndvs", "<f4", 3), ("dndu", "<f4", 3), ("dndv", "<f4", 3),
+                              ("pad0", "<f4"), ("prim", "<i4"), ("status", "<i4"), ("pad1", "<i4", 2)])
 TRI_FLIP_NORMAL, TRI_HAS_UV, TRI_HAS_N, TRI_HAS_S = 1, 2, 4, 8
-assert INTERACTION_DTYPE.itemsize == 160
+assert INTERACTION_DTYPE.itemsize == 192
 assert NODE_DTYPE.itemsize == 32 and PRIM_DTYPE.itemsize == 24
 assert RAY_SOA_DTYPE.itemsize == 72 and CLOSEST_QUEUES_DTYPE.itemsize == 6 * 24
 assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 32
@@ -121,7 +121,7 @@ def lib():
     L.nnbvh_build_gpu_timing.restype = i32
     L.nnbvh_build_gpu_timing.argtypes = [vp, vp]
     L.nnbvh_shading_mesh_create.restype = vp
-    L.nnbvh_shading_mesh_create.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32]
+    L.nnbvh_shading_mesh_create.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32]
     L.nnbvh_shading_mesh_destroy.restype = None
     L.nnbvh_shading_mesh_destroy.argtypes = [vp]
     L.nnbvh_triangle_interactions.restype = i32

@@ -846,7 +846,7 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
 }
 
 // ---- Triangle::InteractionFromIntersection post-pass (shapes.h:884-1010) --------------------------
-static_assert(sizeof(nnbvh_interaction) == 160, "nnbvh_interaction must be 160 bytes");
+static_assert(sizeof(nnbvh_interaction) == 192, "nnbvh_interaction must be 192 bytes");
 
 }  // extern "C"
 
@@ -867,7 +867,8 @@ static bool upload(T **dst, const T *src, size_t count, const char *what) {
 extern "C" {
 
 nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
-                                              const int32_t *tri_vertices, int n_tris,
+                                              const int32_t *tri_vertices,
+                                              const int32_t *patch_vertices, int n_tris,
                                               const float *normals, const float *uvs,
                                               const float *tangents, const int32_t *face_indices,
                                               const uint8_t *tri_flags, int device) {
@@ -880,6 +881,14 @@ nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
         const bool not_a_triangle = tri_vertices[i - i % 3] < 0;
         if (!not_a_triangle && (v < 0 || v >= n_verts)) {
             set_error("shading_mesh_create: vertex index out of range");
+            return nullptr;
+        }
+    }
+    for (long i = 0; patch_vertices && i < 4L * n_tris; ++i) {
+        const int v = patch_vertices[i];
+        const bool not_a_patch = patch_vertices[i - i % 4] < 0;
+        if (!not_a_patch && (v < 0 || v >= n_verts)) {
+            set_error("shading_mesh_create: patch vertex index out of range");
             return nullptr;
         }
     }
@@ -899,6 +908,7 @@ nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
                         (tangents ? NNBVH_TRI_HAS_S : 0);
     const bool ok = upload(&m->d.verts, verts, 3 * (size_t)n_verts, "shading mesh: vertices") &&
                     upload(&m->d.triVerts, tri_vertices, 3 * (size_t)n_tris, "shading mesh: indices") &&
+                    upload(&m->d.patchVerts, patch_vertices, 4 * (size_t)n_tris, "shading mesh: patch indices") &&
                     upload(&m->d.normals, normals, 3 * (size_t)n_verts, "shading mesh: normals") &&
                     upload(&m->d.uvs, uvs, 2 * (size_t)n_verts, "shading mesh: uvs") &&
                     upload(&m->d.tangents, tangents, 3 * (size_t)n_verts, "shading mesh: tangents") &&
@@ -914,7 +924,7 @@ nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
 void nnbvh_shading_mesh_destroy(nnbvh_shading_mesh *m) {
     if (!m) return;
     DeviceGuard guard(m->device);
-    void *ptrs[] = {m->d.verts, m->d.triVerts, m->d.normals, m->d.uvs, m->d.tangents, m->d.faceIndices, m->d.triFlags};
+    void *ptrs[] = {m->d.verts, m->d.triVerts, m->d.patchVerts, m->d.normals, m->d.uvs, m->d.tangents, m->d.faceIndices, m->d.triFlags};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;

@@ -9,7 +9,7 @@ namespace nnbvh {
 
 struct ShadingMeshDevice {  // device pointers of a nnbvh_shading_mesh
     float *verts = nullptr;
-    int32_t *triVerts = nullptr;
+    int32_t *triVerts = nullptr, *patchVerts = nullptr;
     float *normals = nullptr, *uvs = nullptr, *tangents = nullptr;
     int32_t *faceIndices = nullptr;
     uint8_t *triFlags = nullptr;

@@ -1,13 +1,13 @@
-// interaction.hip — Triangle::InteractionFromIntersection on the device
-// (/root/reference/src/pbrt/shapes.h:884-1010, with the SurfaceInteraction constructor and
-// SetShadingGeometry it runs: interaction.h:32-33, 164-214).
+// interaction.hip — Triangle:: and BilinearPatch::InteractionFromIntersection on the device
+// (/root/reference/src/pbrt/shapes.h:884-1010, 1396-1489, with the SurfaceInteraction constructor
+// and SetShadingGeometry they run: interaction.h:32-33, 164-214).
 //
 // The traversal kernels return what TriangleIntersection carries (primitive, b0 b1 b2, t);
 // Triangle::Intersect (shapes.cpp:302-334) then builds the SurfaceInteraction every later stage of
 // the reference reads (wavefront/intersect.h:49-156 copies pi, n, dpdu, dpdv, uv, shading.* and
 // faceIndex into its work items).  This is that post-pass for a whole batch of hit records: one
 // thread per item, ~250 flops, 80-190 B gathered (hit, ray direction + time, 3 vertex indices,
-// 3 positions, optional uv / normal / tangent triples) and 160 B written — a streaming, HBM-bound
+// 3 positions, optional uv / normal / tangent triples) and 192 B written — a streaming, HBM-bound
 // pass a few percent of the trace it follows.
 //
 // Arithmetic is the reference's, operation for operation (FMA exactly where DifferenceOfProducts /
@@ -89,13 +89,154 @@ IDEV float next_down(float v) {
 
 struct MeshView {
     const float *verts;
-    const int32_t *triVerts;
+    const int32_t *triVerts, *patchVerts;
     const float *normals, *uvs, *tangents;
     const int32_t *faceIndices;
     const uint8_t *triFlags;
     int nTris;
     unsigned defaultFlags;
 };
+
+IDEV F3 lerp3(float t, F3 a, F3 b) {  // (1 - t) * a + t * b: vecmath.h:410-412
+    const float s = 1 - t;
+    return {s * a.x + t * b.x, s * a.y + t * b.y, s * a.z + t * b.z};
+}
+IDEV F3 scale_add2(F3 a, float sa, F3 b, float sb) {  // a * sa + b * sb
+    return {sa * a.x + sb * b.x, sa * a.y + sb * b.y, sa * a.z + sb * b.z};
+}
+IDEV float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vecmath.h:964-967
+IDEV float comp(F3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+IDEV void put(float *dst, F3 v) {
+    dst[0] = v.x;
+    dst[1] = v.y;
+    dst[2] = v.z;
+}
+
+// BilinearPatch::InteractionFromIntersection (shapes.h:1396-1489), with RotateFromTo
+// (util/transform.h:249-270) for the shading frame
+IDEV void patch_interaction(const MeshView &m, int prim, float u, float v, F3 wo, float time, nnbvh_interaction &r) {
+    const int v0 = m.patchVerts[4 * (long)prim], v1 = m.patchVerts[4 * (long)prim + 1],
+              v2 = m.patchVerts[4 * (long)prim + 2], v3 = m.patchVerts[4 * (long)prim + 3];
+    const unsigned flags = m.triFlags ? m.triFlags[prim] : m.defaultFlags;
+    const F3 p00 = f3(m.verts + 3 * (long)v0), p10 = f3(m.verts + 3 * (long)v1), p01 = f3(m.verts + 3 * (long)v2),
+             p11 = f3(m.verts + 3 * (long)v3);
+    const F3 a = lerp3(v, p00, p01), b = lerp3(v, p10, p11);
+    const F3 p = lerp3(u, a, b);
+    F3 dpdu = b - a;
+    F3 dpdv = lerp3(u, p01, p11) - lerp3(u, p00, p10);
+    float st0 = u, st1 = v;
+    float duds = 1, dudt = 0, dvds = 0, dvdt = 1;
+    if ((flags & NNBVH_TRI_HAS_UV) && m.uvs) {
+        const float *q00 = m.uvs + 2 * (long)v0, *q10 = m.uvs + 2 * (long)v1, *q01 = m.uvs + 2 * (long)v2,
+                    *q11 = m.uvs + 2 * (long)v3;
+        const float sv = 1 - v, su = 1 - u;
+        const float s0x = sv * q00[0] + v * q01[0], s0y = sv * q00[1] + v * q01[1];
+        const float s1x = sv * q10[0] + v * q11[0], s1y = sv * q10[1] + v * q11[1];
+        st0 = su * s0x + u * s1x;
+        st1 = su * s0y + u * s1y;
+        const float dstdu0 = s1x - s0x, dstdu1 = s1y - s0y;
+        const float t0x = su * q01[0] + u * q11[0], t0y = su * q01[1] + u * q11[1];
+        const float t1x = su * q00[0] + u * q10[0], t1y = su * q00[1] + u * q10[1];
+        const float dstdv0 = t0x - t1x, dstdv1 = t0y - t1y;
+        duds = __builtin_fabsf(dstdu0) < 1e-8f ? 0 : 1 / dstdu0;
+        dvds = __builtin_fabsf(dstdv0) < 1e-8f ? 0 : 1 / dstdv0;
+        dudt = __builtin_fabsf(dstdu1) < 1e-8f ? 0 : 1 / dstdu1;
+        dvdt = __builtin_fabsf(dstdv1) < 1e-8f ? 0 : 1 / dstdv1;
+        const F3 dpds = scale_add2(dpdu, duds, dpdv, dvds);
+        F3 dpdt = scale_add2(dpdu, dudt, dpdv, dvdt);
+        const F3 c1 = cross(dpds, dpdt);
+        if (c1.x != 0 || c1.y != 0 || c1.z != 0) {
+            if (dot3(cross(dpdu, dpdv), c1) < 0) dpdt = neg(dpdt);
+            dpdu = dpds;
+            dpdv = dpdt;
+        }
+    }
+    // fundamental forms (:1441-1456); d2Pduu = d2Pdvv = 0
+    const F3 d2uv = {(p00.x - p01.x) + (p11.x - p10.x), (p00.y - p01.y) + (p11.y - p10.y),
+                     (p00.z - p01.z) + (p11.z - p10.z)};
+    const F3 zero = {0, 0, 0};
+    const float E = dot3(dpdu, dpdu), F = dot3(dpdu, dpdv), G = dot3(dpdv, dpdv);
+    const F3 nn = normalize(cross(dpdu, dpdv));
+    const float e = dot3(nn, zero), f = dot3(nn, d2uv), g = dot3(nn, zero);
+    const float EGF2 = dop(E, G, F, F);
+    const float invEGF2 = (EGF2 == 0) ? 0.0f : 1 / EGF2;
+    F3 dndu = scale_add2(dpdu, (f * F - e * G) * invEGF2, dpdv, (e * F - f * E) * invEGF2);
+    F3 dndv = scale_add2(dpdu, (g * F - f * G) * invEGF2, dpdv, (f * F - g * E) * invEGF2);
+    const F3 dnds = scale_add2(dndu, duds, dndv, dvds), dndt = scale_add2(dndu, dudt, dndv, dvdt);
+    dndu = dnds;
+    dndv = dndt;
+    const float g6 = (6.0f * 0x1p-24f) / (1.0f - 6.0f * 0x1p-24f);
+    const float pe[3] = {
+        g6 * (((__builtin_fabsf(p00.x) + __builtin_fabsf(p01.x)) + __builtin_fabsf(p10.x)) + __builtin_fabsf(p11.x)),
+        g6 * (((__builtin_fabsf(p00.y) + __builtin_fabsf(p01.y)) + __builtin_fabsf(p10.y)) + __builtin_fabsf(p11.y)),
+        g6 * (((__builtin_fabsf(p00.z) + __builtin_fabsf(p01.z)) + __builtin_fabsf(p10.z)) + __builtin_fabsf(p11.z))};
+    // SurfaceInteraction(pi, st, wo, dpdu, dpdv, dndu, dndv, time, flipNormal): interaction.h:164-183
+    F3 nrm = normalize(cross(dpdu, dpdv));
+    if (flags & NNBVH_TRI_FLIP_NORMAL) nrm = {nrm.x * -1, nrm.y * -1, nrm.z * -1};
+    F3 ns = nrm, sdpdu = dpdu, sdpdv = dpdv, sdndu = dndu, sdndv = dndv;
+    if ((flags & NNBVH_TRI_HAS_N) && m.normals) {
+        const F3 n00 = f3(m.normals + 3 * (long)v0), n10 = f3(m.normals + 3 * (long)v1),
+                 n01 = f3(m.normals + 3 * (long)v2), n11 = f3(m.normals + 3 * (long)v3);
+        const F3 a0 = lerp3(v, n00, n01), a1 = lerp3(v, n10, n11);
+        const F3 nsv = lerp3(u, a0, a1);
+        if (len2(nsv) > 0) {
+            const F3 nsn = normalize(nsv);
+            const F3 du = a1 - a0;
+            const F3 dv = lerp3(u, n01, n11) - lerp3(u, n00, n10);
+            const F3 ds = scale_add2(du, duds, dv, dvds), dt = scale_add2(du, dudt, dv, dvdt);
+            const F3 from = normalize(nrm);
+            F3 refl = {0, 0, 0};
+            if (__builtin_fabsf(from.x) < 0.72f && __builtin_fabsf(nsn.x) < 0.72f) refl.x = 1;
+            else if (__builtin_fabsf(from.y) < 0.72f && __builtin_fabsf(nsn.y) < 0.72f) refl.y = 1;
+            else refl.z = 1;
+            const F3 uu = refl - from, vv = refl - nsn;
+            const float duu = dot3(uu, uu), dvv = dot3(vv, vv), duv = dot3(uu, vv);
+            float rd[3], re[3];
+            for (int i = 0; i < 3; ++i) {
+                float row[3];
+                for (int j = 0; j < 3; ++j)
+                    row[j] = ((i == j) ? 1 : 0) - 2 / duu * comp(uu, i) * comp(uu, j) -
+                             2 / dvv * comp(vv, i) * comp(vv, j) + 4 * duv / (duu * dvv) * comp(vv, i) * comp(uu, j);
+                rd[i] = row[0] * dpdu.x + row[1] * dpdu.y + row[2] * dpdu.z;
+                re[i] = row[0] * dpdv.x + row[1] * dpdv.y + row[2] * dpdv.z;
+            }
+            // SetShadingGeometry(ns, r(dpdu), r(dpdv), dndu, dndv, true)
+            ns = nsn;
+            if (dot_n(nrm, ns) < 0.f) nrm = neg(nrm);
+            sdpdu = {rd[0], rd[1], rd[2]};
+            sdpdv = {re[0], re[1], re[2]};
+            sdndu = ds;
+            sdndv = dt;
+            while (len2(sdpdu) > 1e16f || len2(sdpdv) > 1e16f) {
+                sdpdu = {sdpdu.x / 1e8f, sdpdu.y / 1e8f, sdpdu.z / 1e8f};
+                sdpdv = {sdpdv.x / 1e8f, sdpdv.y / 1e8f, sdpdv.z / 1e8f};
+            }
+        }
+    }
+    const float ph[3] = {p.x, p.y, p.z};
+    for (int k = 0; k < 3; ++k) {
+        if (pe[k] == 0) {
+            r.pi_lo[k] = r.pi_hi[k] = ph[k];
+        } else {
+            r.pi_lo[k] = next_down(ph[k] + (-pe[k]));
+            r.pi_hi[k] = next_up(ph[k] + pe[k]);
+        }
+    }
+    r.uv[0] = st0, r.uv[1] = st1;
+    put(r.wo, normalize(wo));
+    r.time = time;
+    put(r.n, nrm);
+    r.face_index = m.faceIndices ? m.faceIndices[prim] : 0;
+    put(r.dpdu, dpdu);
+    put(r.dpdv, dpdv);
+    put(r.ns, ns);
+    put(r.dpdus, sdpdu);
+    put(r.dpdvs, sdpdv);
+    put(r.dndus, sdndu);
+    put(r.dndvs, sdndv);
+    put(r.dndu, dndu);
+    put(r.dndv, dndv);
+}
 
 __global__ __launch_bounds__(256) void k_triangle_interactions(
     MeshView m, const float4 *__restrict__ rays, nnbvh_ray_soa soa, const float4 *__restrict__ hits, int n,
@@ -112,13 +253,16 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
         r.prim = prim;
         r.status = NNBVH_INTERACTION_MISS;
         if (prim >= 0) {
-            const bool hostCase = __float_as_int(h1.w) != 0 || prim >= m.nTris || m.triVerts[3 * (long)prim] < 0;
-            r.status = hostCase ? NNBVH_INTERACTION_HOST : NNBVH_INTERACTION_TRIANGLE;
+            r.status = NNBVH_INTERACTION_HOST;
+            if (__float_as_int(h1.w) == 0 && prim < m.nTris) {
+                if (m.triVerts[3 * (long)prim] >= 0) r.status = NNBVH_INTERACTION_TRIANGLE;
+                else if (m.patchVerts && m.patchVerts[4 * (long)prim] >= 0) r.status = NNBVH_INTERACTION_PATCH;
+            }
         }
-        if (r.status != NNBVH_INTERACTION_TRIANGLE) {
-            // only prim / status are meaningful: store the record's last 16 B {dndvs.z, prim, status, pad}
-            reinterpret_cast<float4 *>(out + i)[9] =
-                make_float4(0.0f, __int_as_float(prim), __int_as_float(r.status), 0.0f);
+        if (r.status != NNBVH_INTERACTION_TRIANGLE && r.status != NNBVH_INTERACTION_PATCH) {
+            // only prim / status are meaningful: store the record's last 16 B {prim, status, 0, 0}
+            reinterpret_cast<float4 *>(out + i)[11] =
+                make_float4(__int_as_float(prim), __int_as_float(r.status), 0.0f, 0.0f);
             continue;
         }
         F3 wo;
@@ -130,6 +274,11 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
         } else {
             wo = {-soa.dx[i], -soa.dy[i], -soa.dz[i]};
             time = soa.time ? soa.time[i] : 0.0f;
+        }
+        if (r.status == NNBVH_INTERACTION_PATCH) {
+            patch_interaction(m, prim, h0.z, h0.w, wo, time, r);
+            out[i] = r;
+            continue;
         }
         const float b0 = h0.z, b1 = h0.w, b2 = h1.x;
         const int v0 = m.triVerts[3 * (long)prim], v1 = m.triVerts[3 * (long)prim + 1],
@@ -168,8 +317,8 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
                 // the reference CHECK-aborts on a zero normal here; IntersectTriangle never reports
                 // such a triangle as hit, so the record is simply marked for the host
                 if (len2(ng) == 0) {
-                    reinterpret_cast<float4 *>(out + i)[9] =
-                        make_float4(0.0f, __int_as_float(prim), __int_as_float(NNBVH_INTERACTION_HOST), 0.0f);
+                    reinterpret_cast<float4 *>(out + i)[11] =
+                        make_float4(__int_as_float(prim), __int_as_float(NNBVH_INTERACTION_HOST), 0.0f, 0.0f);
                     continue;
                 }
             }
@@ -255,7 +404,7 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
 hipError_t launch_triangle_interactions(const ShadingMeshDevice &m, const void *rays, const nnbvh_ray_soa *soa,
                                         const void *hits, int n, const int32_t *nDev, void *out, int maxBlocks,
                                         hipStream_t stream) {
-    MeshView v{m.verts, m.triVerts, m.normals, m.uvs, m.tangents, m.faceIndices, m.triFlags, m.nTris, m.defaultFlags};
+    MeshView v{m.verts, m.triVerts, m.patchVerts, m.normals, m.uvs, m.tangents, m.faceIndices, m.triFlags, m.nTris, m.defaultFlags};
     nnbvh_ray_soa s;
     __builtin_memset(&s, 0, sizeof s);
     if (soa) s = *soa;

@@ -1,5 +1,5 @@
-"""Host-side mirror of the hit -> SurfaceInteraction post-pass
-(Triangle::InteractionFromIntersection, /root/reference/src/pbrt/shapes.h:884-1010) over
+"""Host-side mirror of the hit -> SurfaceInteraction post-pass (Triangle:: and
+BilinearPatch::InteractionFromIntersection, /root/reference/src/pbrt/shapes.h:884-1010, 1396-1489) over
 include/nnbvh.h's nnbvh_shading_mesh_* / nnbvh_triangle_interactions_device."""
 import numpy as np
 
@@ -13,17 +13,22 @@ class ShadingMesh:
     arrays, in render space and as the TriangleMesh constructor stores them."""
 
     def __init__(self, verts, tri_vertices, normals=None, uvs=None, tangents=None, face_indices=None,
-                 tri_flags=None, device=0):
+                 tri_flags=None, device=0, patch_vertices=None):
         f32 = lambda a, w: None if a is None else np.ascontiguousarray(a, np.float32).reshape(-1, w)  # noqa: E731
         self.verts = f32(verts, 3)
         self.tri_vertices = np.ascontiguousarray(tri_vertices, np.int32).reshape(-1, 3)
+        self.patch_vertices = None
+        if patch_vertices is not None:  # 4 per primitive (p00 p10 p01 p11), v[0] < 0: not a patch
+            self.patch_vertices = np.ascontiguousarray(patch_vertices, np.int32).reshape(-1, 4)
+            assert len(self.patch_vertices) == len(self.tri_vertices)
         self.normals, self.uvs, self.tangents = f32(normals, 3), f32(uvs, 2), f32(tangents, 3)
         self.face_indices = None if face_indices is None else np.ascontiguousarray(face_indices, np.int32)
         self.tri_flags = None if tri_flags is None else np.ascontiguousarray(tri_flags, np.uint8)
         self.device = int(device)
         opt = lambda a: ptr(a) if a is not None else None  # noqa: E731
         self._h = _lib.lib().nnbvh_shading_mesh_create(
-            ptr(self.verts), len(self.verts), ptr(self.tri_vertices), len(self.tri_vertices),
+            ptr(self.verts), len(self.verts), ptr(self.tri_vertices), opt(self.patch_vertices),
+            len(self.tri_vertices),
             opt(self.normals), opt(self.uvs), opt(self.tangents), opt(self.face_indices),
             opt(self.tri_flags), self.device)
         if not self._h:

@@ -1048,3 +1048,200 @@ void orc_triangle_interaction_batch(const float *in45, int n, float *out44) {
                                  out44 + 44 * (size_t)i);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * BilinearPatch::InteractionFromIntersection (shapes.h:1396-1489) + RotateFromTo
+ * (util/transform.h:249-270) + the SurfaceInteraction constructor / SetShadingGeometry.
+ * p12 = p00 p10 p01 p11; uv8 / n12 in the same vertex order, NULL = mesh without that attribute;
+ * hit_uv = the (u, v) of BilinearIntersection.  Output record (50 floats): [0..43] as
+ * orc_triangle_interaction, [44..46] geometric dndu, [47..49] geometric dndv. */
+static inline void orc_lerp_n(float t, const float *a, const float *b, int dim, float *out) {
+    /* Lerp(t, a, b) = (1 - t) * a + t * b  (vecmath.h:203-205, 410-412) */
+    const float s = 1 - t;
+    for (int k = 0; k < dim; ++k) out[k] = s * a[k] + t * b[k];
+}
+static inline void orc_scale_add2(const float a[3], float sa, const float b[3], float sb, float out[3]) {
+    /* a * sa + b * sb with Tuple3::operator*(U s) = {s * x, ...} (vecmath.h:350-353) */
+    for (int k = 0; k < 3; ++k) out[k] = sa * a[k] + sb * b[k];
+}
+
+/* rare-branch counters of orc_patch_interaction: 0 (s,t) derivatives adopted, 1 dpdt negated, 2 a
+ * 1e-8 derivative test zeroed a factor, 3 zero interpolated normal, 4 / 5 reflection about y / z in
+ * RotateFromTo, 6 geometric normal flipped to the shading side, 7 cross(dpds, dpdt) == 0 */
+long orc_patch_branches[8];
+
+int orc_patch_interaction(const float p12[12], const float *uv8, const float *n12, int flip_normal,
+                          const float hit_uv[2], const float wo[3], float time, int face_index,
+                          float out[50]) {
+    const float *p00 = p12, *p10 = p12 + 3, *p01 = p12 + 6, *p11 = p12 + 9;
+    const float u = hit_uv[0], v = hit_uv[1];
+    float a[3], b[3], p[3], dpdu[3], dpdv[3];
+    orc_lerp_n(v, p00, p01, 3, a);
+    orc_lerp_n(v, p10, p11, 3, b);
+    orc_lerp_n(u, a, b, 3, p);
+    for (int k = 0; k < 3; ++k) dpdu[k] = b[k] - a[k];
+    orc_lerp_n(u, p01, p11, 3, a);
+    orc_lerp_n(u, p00, p10, 3, b);
+    for (int k = 0; k < 3; ++k) dpdv[k] = a[k] - b[k];
+    float st[2] = {u, v};
+    float duds = 1, dudt = 0, dvds = 0, dvdt = 1;
+    if (uv8) {
+        const float *uv00 = uv8, *uv10 = uv8 + 2, *uv01 = uv8 + 4, *uv11 = uv8 + 6;
+        float s0[2], s1[2], dstdu[2], dstdv[2];
+        orc_lerp_n(v, uv00, uv01, 2, s0);
+        orc_lerp_n(v, uv10, uv11, 2, s1);
+        orc_lerp_n(u, s0, s1, 2, st);
+        for (int k = 0; k < 2; ++k) dstdu[k] = s1[k] - s0[k];
+        orc_lerp_n(u, uv01, uv11, 2, s0);
+        orc_lerp_n(u, uv00, uv10, 2, s1);
+        for (int k = 0; k < 2; ++k) dstdv[k] = s0[k] - s1[k];
+        duds = fabsf(dstdu[0]) < 1e-8f ? 0 : 1 / dstdu[0];
+        dvds = fabsf(dstdv[0]) < 1e-8f ? 0 : 1 / dstdv[0];
+        dudt = fabsf(dstdu[1]) < 1e-8f ? 0 : 1 / dstdu[1];
+        dvdt = fabsf(dstdv[1]) < 1e-8f ? 0 : 1 / dstdv[1];
+        if (duds == 0 || dvds == 0 || dudt == 0 || dvdt == 0) ++orc_patch_branches[2];
+        float dpds[3], dpdt[3], c1[3], c0[3];
+        orc_scale_add2(dpdu, duds, dpdv, dvds, dpds);
+        orc_scale_add2(dpdu, dudt, dpdv, dvdt, dpdt);
+        orc_cross(dpds, dpdt, c1);
+        if (c1[0] != 0 || c1[1] != 0 || c1[2] != 0) {
+            orc_cross(dpdu, dpdv, c0);
+            ++orc_patch_branches[0];
+            if (orc_dot(c0, c1) < 0) {
+                for (int k = 0; k < 3; ++k) dpdt[k] = -dpdt[k];
+                ++orc_patch_branches[1];
+            }
+            memcpy(dpdu, dpds, 12);
+            memcpy(dpdv, dpdt, 12);
+        } else
+            ++orc_patch_branches[7];
+    }
+    /* fundamental forms (:1441-1456); d2Pduu = d2Pdvv = 0 */
+    float d2uv[3], zero[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) d2uv[k] = (p00[k] - p01[k]) + (p11[k] - p10[k]);
+    const float E = orc_dot(dpdu, dpdu), F = orc_dot(dpdu, dpdv), G = orc_dot(dpdv, dpdv);
+    float cr[3], nn[3];
+    orc_cross(dpdu, dpdv, cr);
+    orc_normalize(cr, nn);
+    const float e = orc_dot(nn, zero), f = orc_dot(nn, d2uv), g = orc_dot(nn, zero);
+    const float EGF2 = orc_dop(E, G, F, F);
+    const float invEGF2 = (EGF2 == 0) ? 0.0f : 1 / EGF2;
+    float dndu[3], dndv[3], dnds[3], dndt[3];
+    orc_scale_add2(dpdu, (f * F - e * G) * invEGF2, dpdv, (e * F - f * E) * invEGF2, dndu);
+    orc_scale_add2(dpdu, (g * F - f * G) * invEGF2, dpdv, (f * F - g * E) * invEGF2, dndv);
+    orc_scale_add2(dndu, duds, dndv, dvds, dnds);
+    orc_scale_add2(dndu, dudt, dndv, dvdt, dndt);
+    memcpy(dndu, dnds, 12);
+    memcpy(dndv, dndt, 12);
+    float p_err[3];
+    for (int k = 0; k < 3; ++k) {
+        float s = ((fabsf(p00[k]) + fabsf(p01[k])) + fabsf(p10[k])) + fabsf(p11[k]);
+        p_err[k] = orc_gamma(6) * s;
+    }
+    /* SurfaceInteraction(pi, st, wo, dpdu, dpdv, dndu, dndv, time, flipNormal): interaction.h:164-183 */
+    float n[3], ns[3], sdpdu[3], sdpdv[3], sdndu[3], sdndv[3];
+    orc_cross(dpdu, dpdv, cr);
+    orc_normalize(cr, n);
+    if (flip_normal)
+        for (int k = 0; k < 3; ++k) n[k] *= -1;
+    memcpy(ns, n, 12);
+    memcpy(sdpdu, dpdu, 12);
+    memcpy(sdpdv, dpdv, 12);
+    memcpy(sdndu, dndu, 12);
+    memcpy(sdndv, dndv, 12);
+    if (n12) {
+        const float *n00 = n12, *n10 = n12 + 3, *n01 = n12 + 6, *n11 = n12 + 9;
+        float a0[3], a1[3], nsv[3];
+        orc_lerp_n(v, n00, n01, 3, a0);
+        orc_lerp_n(v, n10, n11, 3, a1);
+        orc_lerp_n(u, a0, a1, 3, nsv);
+        if (!(orc_len2(nsv) > 0)) ++orc_patch_branches[3];
+        if (orc_len2(nsv) > 0) {
+            float nsn[3], du[3], dv[3], ds[3], dt[3];
+            orc_normalize(nsv, nsn);
+            for (int k = 0; k < 3; ++k) du[k] = a1[k] - a0[k];
+            orc_lerp_n(u, n01, n11, 3, a0);
+            orc_lerp_n(u, n00, n10, 3, a1);
+            for (int k = 0; k < 3; ++k) dv[k] = a0[k] - a1[k];
+            orc_scale_add2(du, duds, dv, dvds, ds);
+            orc_scale_add2(du, dudt, dv, dvdt, dt);
+            /* RotateFromTo(Normalize(isect.n), ns): util/transform.h:249-270 */
+            float from[3], refl[3] = {0, 0, 0}, uu[3], vv[3], r[3][3];
+            orc_normalize(n, from);
+            if (fabsf(from[0]) < 0.72f && fabsf(nsn[0]) < 0.72f) refl[0] = 1;
+            else if (fabsf(from[1]) < 0.72f && fabsf(nsn[1]) < 0.72f) {
+                refl[1] = 1;
+                ++orc_patch_branches[4];
+            } else {
+                refl[2] = 1;
+                ++orc_patch_branches[5];
+            }
+            for (int k = 0; k < 3; ++k) {
+                uu[k] = refl[k] - from[k];
+                vv[k] = refl[k] - nsn[k];
+            }
+            const float duu = orc_dot(uu, uu), dvv = orc_dot(vv, vv), duv = orc_dot(uu, vv);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    r[i][j] = ((i == j) ? 1 : 0) - 2 / duu * uu[i] * uu[j] - 2 / dvv * vv[i] * vv[j] +
+                              4 * duv / (duu * dvv) * vv[i] * uu[j];
+            float rdpdu[3], rdpdv[3];
+            for (int i = 0; i < 3; ++i) {
+                rdpdu[i] = r[i][0] * dpdu[0] + r[i][1] * dpdu[1] + r[i][2] * dpdu[2];
+                rdpdv[i] = r[i][0] * dpdv[0] + r[i][1] * dpdv[1] + r[i][2] * dpdv[2];
+            }
+            /* SetShadingGeometry(ns, r(dpdu), r(dpdv), dndu, dndv, true) */
+            memcpy(ns, nsn, 12);
+            if (orc_dot_n(n, ns) < 0.f) {
+                for (int k = 0; k < 3; ++k) n[k] = -n[k];
+                ++orc_patch_branches[6];
+            }
+            memcpy(sdpdu, rdpdu, 12);
+            memcpy(sdpdv, rdpdv, 12);
+            memcpy(sdndu, ds, 12);
+            memcpy(sdndv, dt, 12);
+            while (orc_len2(sdpdu) > 1e16f || orc_len2(sdpdv) > 1e16f)
+                for (int k = 0; k < 3; ++k) {
+                    sdpdu[k] /= 1e8f;
+                    sdpdv[k] /= 1e8f;
+                }
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        orc_ivl iv = ivl_from_value_and_error(p[k], p_err[k]);
+        out[k] = (iv.lo + iv.hi) / 2;
+        out[3 + k] = (iv.hi - iv.lo) / 2;
+        out[38 + k] = iv.lo;
+        out[41 + k] = iv.hi;
+        out[11 + k] = n[k];
+        out[14 + k] = dpdu[k];
+        out[17 + k] = dpdv[k];
+        out[20 + k] = ns[k];
+        out[23 + k] = sdpdu[k];
+        out[26 + k] = sdpdv[k];
+        out[29 + k] = sdndu[k];
+        out[32 + k] = sdndv[k];
+        out[44 + k] = dndu[k];
+        out[47 + k] = dndv[k];
+    }
+    orc_normalize(wo, out + 8);
+    out[6] = st[0];
+    out[7] = st[1];
+    out[35] = time;
+    out[36] = (float)face_index;
+    out[37] = 0;
+    return 1;
+}
+
+/* records as oracle/ref_interaction.cpp's "blp" mode reads them (40 floats); normals negated under
+ * reverseOrientation like the BilinearPatchMesh constructor does (util/mesh.cpp:216-223) */
+void orc_patch_interaction_batch(const float *in40, int n, float *out50) {
+    for (int i = 0; i < n; ++i) {
+        const float *r = in40 + 40 * (size_t)i;
+        int flags = (int)r[18];
+        float nn[12];
+        for (int k = 0; k < 12; ++k) nn[k] = (flags & 8) ? -r[27 + k] : r[27 + k];
+        orc_patch_interaction(r, (flags & 1) ? r + 19 : NULL, (flags & 2) ? nn : NULL, (flags & 8) != 0, r + 12,
+                              r + 14, r[17], 7 + i, out50 + 50 * (size_t)i);
+    }
+}

@@ -122,6 +122,13 @@ int orc_triangle_interaction(const float p9[9], const float *uv6, const float *n
                              int face_index, float out[44]);
 void orc_triangle_interaction_batch(const float *in45, int n, float *out44);
 
+/* BilinearPatch::InteractionFromIntersection (shapes.h:1396-1489): 50-float record = the 44 above +
+ * geometric dndu[3], dndv[3]; p12 = p00 p10 p01 p11 */
+int orc_patch_interaction(const float p12[12], const float *uv8, const float *n12, int flip_normal,
+                          const float hit_uv[2], const float wo[3], float time, int face_index,
+                          float out[50]);
+void orc_patch_interaction_batch(const float *in40, int n, float *out50);
+
 /* brute force closest hit over all prims in index order (no BVH): a second,
  * tree-independent check of t for the traversal restatement. */
 void orc_brute_closest(const orc_prim *prims, int n_prims, const float *verts,

@@ -64,3 +64,51 @@ def cases(n, seed):
     rec[k, 20:26] = (rng.uniform(-1, 1, size=(int(k.sum()), 6)) * 1e8).astype(np.float32)
     rec[k, 19] = (rec[k, 19].astype(np.int32) | 1).astype(np.float32)
     return rec
+
+
+def patch_cases(n, seed):
+    """BilinearPatch::InteractionFromIntersection inputs (oracle/ref_interaction.cpp "blp" layout):
+    p00 p10 p01 p11 [0:12], hit (u, v) [12:14], wo [14:17], time [17], flags [18] (1 = uv, 2 = n,
+    8 = reverseOrientation), uv00 uv10 uv01 uv11 [19:27], n00 n10 n01 n11 [27:39]."""
+    rng = np.random.default_rng(seed)
+    rec = np.zeros((n, 40), np.float32)
+    scale = 10.0 ** rng.uniform(-2, 2, size=(n, 1))
+    base = rng.uniform(-1, 1, size=(n, 3)) * scale
+    eu = rng.normal(size=(n, 3)) * scale
+    ev = rng.normal(size=(n, 3)) * scale
+    kind = rng.integers(0, 12, size=n)
+    tw = rng.normal(size=(n, 3)) * scale * 0.3
+    tw[kind == 0] = 0                                   # planar (parallelogram): d2Pduv = 0
+    rec[:, 0:3], rec[:, 3:6], rec[:, 6:9], rec[:, 9:12] = base, base + eu, base + ev, base + eu + ev + tw
+    uvh = rng.random((n, 2))
+    uvh[kind == 1] = np.round(uvh[kind == 1])            # hits on a corner
+    rec[:, 12:14] = uvh
+    rec[:, 14:17] = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-2, 2, size=(n, 1))
+    rec[:, 17] = rng.random(n)
+    rec[:, 18] = rng.choice([0, 1, 2, 3, 8, 9, 10, 11], size=n)
+    # texture coordinates: the natural ones (+ noise), rotated / mirrored ones, degenerate ones
+    nat = np.array([0, 0, 1, 0, 0, 1, 1, 1], np.float64)
+    uv = nat[None] + rng.normal(size=(n, 8)) * 0.05
+    k = kind == 2                                       # mirrored in s: cross(dpds, dpdt) flips
+    uv[k, 0::2] = 1 - uv[k, 0::2]
+    k = kind == 3                                       # s does not vary with u along one edge
+    uv[k, 2] = uv[k, 0]
+    uv[k, 6] = uv[k, 4]
+    k = kind == 4                                       # all corners share one (s, t)
+    uv[k] = np.tile(uv[k, 0:2], 4)
+    k = kind == 5                                       # swapped axes
+    uv[k] = uv[k][:, [0, 1, 4, 5, 2, 3, 6, 7]]
+    rec[:, 19:27] = uv
+    nrm = rng.normal(size=(n, 4, 3))
+    nrm /= np.linalg.norm(nrm, axis=2, keepdims=True)
+    k = kind == 6                                       # interpolated normal exactly zero
+    nrm[k] = 0
+    k = kind == 7                                       # normals near +-x / +-y: the other reflection axes
+    nrm[k] = np.float64([1, 0.02, 0.01]) * rng.choice([-1, 1], size=(int(k.sum()), 1, 1))
+    k = kind == 8
+    nrm[k] = np.float64([0.9, 0.9, 0.05]) / np.linalg.norm([0.9, 0.9, 0.05])
+    rec[k, 0:3], rec[k, 3:6] = base[k], base[k] + np.float64([0, 0, 1]) * scale[k]   # patch facing +-x / y
+    rec[k, 6:9] = base[k] + np.float64([0.7, -0.7, 0]) * scale[k]
+    rec[k, 9:12] = rec[k, 3:6] + np.float64([0.7, -0.7, 0]) * scale[k]
+    rec[:, 27:39] = nrm.reshape(n, 12)
+    return rec

@@ -14,17 +14,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.path.join(ROOT, "oracle", "_ref", "ref_interaction")
 sys.path.insert(0, HERE)
-from interaction_cases import cases  # noqa: E402
+from interaction_cases import cases, patch_cases  # noqa: E402
 
 
-def run_ref(rec):
+def run_ref(rec, mode="tri"):
     with tempfile.TemporaryDirectory() as td:
         fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         with open(fi, "wb") as f:
             f.write(np.int32(len(rec)).tobytes())
             f.write(np.ascontiguousarray(rec, np.float32).tobytes())
-        subprocess.run([REF, fi, fo], check=True)
-        return np.fromfile(fo, dtype=np.uint32).reshape(len(rec), 44)
+        subprocess.run([REF, mode, fi, fo], check=True)
+        return np.fromfile(fo, dtype=np.uint32).reshape(len(rec), 44 if mode == "tri" else 50)
 
 
 if __name__ == "__main__":
@@ -32,3 +32,7 @@ if __name__ == "__main__":
     out = run_ref(rec)
     np.savez_compressed(os.path.join(HERE, "tri_interaction.npz"), inputs=rec, outputs=out)
     print("tri_interaction.npz:", rec.shape, out.shape)
+    rec = patch_cases(3072, 20240608)
+    out = run_ref(rec, "blp")
+    np.savez_compressed(os.path.join(HERE, "blp_interaction.npz"), inputs=rec, outputs=out)
+    print("blp_interaction.npz:", rec.shape, out.shape)

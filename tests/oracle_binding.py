@@ -179,3 +179,20 @@ def interaction_branches(reset=False):
         for k in range(9):
             arr[k] = 0
     return vals
+
+
+def patch_interaction_batch(records40):
+    """orc_patch_interaction_batch on oracle/ref_interaction.cpp "blp" records -> float32 [n, 50]."""
+    rec = np.ascontiguousarray(records40, np.float32).reshape(-1, 40)
+    out = np.zeros((len(rec), 50), np.float32)
+    lib().orc_patch_interaction_batch(_p(rec), ctypes.c_int(len(rec)), _p(out))
+    return out
+
+
+def patch_branches(reset=False):
+    arr = (ctypes.c_long * 8).in_dll(lib(), "orc_patch_branches")
+    vals = list(arr)
+    if reset:
+        for k in range(8):
+            arr[k] = 0
+    return vals

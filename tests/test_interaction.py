@@ -17,7 +17,7 @@ import oracle_binding as ob
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
-from interaction_cases import cases  # noqa: E402
+from interaction_cases import cases, patch_cases  # noqa: E402
 
 GOLDEN = os.path.join(HERE, "golden", "tri_interaction.npz")
 REF = os.path.join(HERE, "..", "oracle", "_ref", "ref_interaction")
@@ -52,6 +52,59 @@ def test_oracle_equals_reference_live(seed):
     out = ob.triangle_interaction_batch(rec)
     # faceIndex is 7 + record number in both
     assert np.array_equal(out.view(np.uint32), ref)
+
+
+def test_oracle_patch_interaction_matches_reference_vectors_bit_exact():
+    g = np.load(os.path.join(HERE, "golden", "blp_interaction.npz"))
+    ob.patch_branches(reset=True)
+    out = ob.patch_interaction_batch(g["inputs"])
+    bad = np.nonzero(out.view(np.uint32) != g["outputs"])
+    assert len(bad[0]) == 0, f"{len(bad[0])} words differ, first rows {bad[0][:5]} cols {bad[1][:5]}"
+    assert min(ob.patch_branches()) > 0, ob.patch_branches()
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.isdir("/root/reference")),
+                    reason="compiled reference harness only exists in the build container")
+def test_oracle_patch_interaction_equals_reference_live():
+    rec = patch_cases(20000, 5)
+    with tempfile.TemporaryDirectory() as td:
+        fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fi, "wb") as f:
+            f.write(np.int32(len(rec)).tobytes())
+            f.write(rec.tobytes())
+        subprocess.run([REF, "blp", fi, fo], check=True)
+        ref = np.fromfile(fo, dtype=np.uint32).reshape(len(rec), 50)
+    assert np.array_equal(ob.patch_interaction_batch(rec).view(np.uint32), ref)
+
+
+@pytest.mark.gpu
+def test_gpu_patch_interactions_match_oracle_on_reference_vectors():
+    from nn_bvh_amd import HIT_DTYPE, RAY_DTYPE, _lib
+    from nn_bvh_amd.interaction import ShadingMesh
+    rec = np.load(os.path.join(HERE, "golden", "blp_interaction.npz"))["inputs"]
+    n = len(rec)
+    exp = ob.patch_interaction_batch(rec)
+    flags_in = rec[:, 18].astype(np.int32)
+    normals = rec[:, 27:39].reshape(-1, 3).copy()
+    normals[np.repeat((flags_in & 8) != 0, 4)] *= -1  # util/mesh.cpp:216-223
+    tri_flags = (((flags_in & 1) != 0) * _lib.TRI_HAS_UV + ((flags_in & 2) != 0) * _lib.TRI_HAS_N +
+                 ((flags_in & 8) != 0) * _lib.TRI_FLIP_NORMAL).astype(np.uint8)
+    mesh = ShadingMesh(rec[:, 0:12].reshape(-1, 3), np.full((n, 3), -1, np.int32), normals=normals,
+                       uvs=rec[:, 19:27].reshape(-1, 2), face_indices=7 + np.arange(n, dtype=np.int32),
+                       tri_flags=tri_flags, patch_vertices=np.arange(4 * n, dtype=np.int32).reshape(n, 4))
+    hits = np.zeros(n, HIT_DTYPE)
+    hits["prim"] = np.arange(n)
+    hits["b0"], hits["b1"] = rec[:, 12], rec[:, 13]
+    hits["t"] = 1.0
+    rays = np.zeros(n, RAY_DTYPE)
+    rays["d"] = -rec[:, 14:17]
+    rays["time"] = rec[:, 17]
+    got = mesh.interactions(rays, hits)
+    assert (got["status"] == 3).all()
+    assert_records_equal(got, exp, np.arange(n), "patch golden inputs")
+    for name, sl in (("dndu", slice(44, 47)), ("dndv", slice(47, 50))):
+        assert np.array_equal(got[name].view(np.uint32), exp[:, sl].view(np.uint32)), name
+    mesh.close()
 
 
 def mesh_from_records(rec):
@@ -121,7 +174,9 @@ def test_gpu_interactions_of_traced_hits_soa_queue_and_statuses():
     uvs = rng.random((len(allv), 2)).astype(np.float32)
     tri_vertices = np.full((len(allp), 3), -1, np.int32)
     tri_vertices[allp["id"][allp["kind"] == 0]] = allp["v"][allp["kind"] == 0][:, :3]
-    mesh = ShadingMesh(allv, tri_vertices, normals=normals, uvs=uvs)
+    patch_vertices = np.full((len(allp), 4), -1, np.int32)
+    patch_vertices[allp["id"][allp["kind"] == 1]] = allp["v"][allp["kind"] == 1]
+    mesh = ShadingMesh(allv, tri_vertices, normals=normals, uvs=uvs, patch_vertices=patch_vertices)
     tree = build_tree(allp, allv)
     agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, allv)
     n = 20000
@@ -133,18 +188,18 @@ def test_gpu_interactions_of_traced_hits_soa_queue_and_statuses():
     size = n - 123
     rq.size.fill_(size)
     hits_t = WavefrontAggregate(agg).IntersectClosest(n, rq)
-    out = torch.full((n * 160,), 0x5A, dtype=torch.uint8, device=dev)
+    out = torch.full((n * 192,), 0x5A, dtype=torch.uint8, device=dev)
     mesh.interactions_device(hits_t.data_ptr(), n, out.data_ptr(), ray_queue=rq, d_size=rq.size.data_ptr(),
                              stream=torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize()
     got = out.cpu().numpy().view(_lib.INTERACTION_DTYPE)
     hits = hits_t.cpu().numpy().view(HIT_DTYPE).reshape(-1)[:size]
-    assert (out.cpu().numpy()[size * 160:] == 0x5A).all(), "records beyond the queue size were written"
+    assert (out.cpu().numpy()[size * 192:] == 0x5A).all(), "records beyond the queue size were written"
     is_tri = (hits["prim"] >= 0) & (hits["prim"] < len(prims))
     is_patch = hits["prim"] >= len(prims)
     assert is_tri.sum() > 1000 and is_patch.sum() > 10 and (hits["prim"] < 0).sum() > 1000
     assert (got["status"][:size][hits["prim"] < 0] == 0).all()
-    assert (got["status"][:size][is_patch] == 2).all()
+    assert (got["status"][:size][is_patch] == 3).all()
     assert (got["status"][:size][is_tri] == 1).all()
     # oracle records for the triangle hits
     rows = np.nonzero(is_tri)[0]
@@ -162,5 +217,24 @@ def test_gpu_interactions_of_traced_hits_soa_queue_and_statuses():
     full = np.zeros((size, 44), np.float32)
     full[rows] = exp
     assert_records_equal(got[:size], full, rows, "traced hits")
+    assert not got["dndu"][rows].any() and not got["dndv"][rows].any()  # Triangle passes Normal3f()
+    # ... and for the hits on bilinear patches (BilinearPatch::InteractionFromIntersection)
+    prow = np.nonzero(is_patch)[0]
+    prec = np.zeros((len(prow), 40), np.float32)
+    pv = patch_vertices[hits["prim"][prow]]
+    prec[:, 0:12] = allv[pv].reshape(-1, 12)
+    prec[:, 12], prec[:, 13] = hits["b0"][prow], hits["b1"][prow]
+    prec[:, 14:17] = -rays["d"][prow]
+    prec[:, 17] = rays["time"][prow]
+    prec[:, 18] = 3
+    prec[:, 19:27] = uvs[pv].reshape(-1, 8)
+    prec[:, 27:39] = normals[pv].reshape(-1, 12)
+    pexp = ob.patch_interaction_batch(prec)
+    pexp[:, 36] = 0
+    pfull = np.zeros((size, 50), np.float32)
+    pfull[prow] = pexp
+    assert_records_equal(got[:size], pfull, prow, "traced patch hits")
+    for name, sl in (("dndu", slice(44, 47)), ("dndv", slice(47, 50))):
+        assert np.array_equal(got[name][prow].view(np.uint32), pexp[:, sl].view(np.uint32)), name
     agg.close()
     mesh.close()
