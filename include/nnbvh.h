@@ -290,13 +290,20 @@ nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
                                               const float *normals, const float *uvs,
                                               const float *tangents, const int32_t *face_indices,
                                               const uint8_t *tri_flags, int device);
+/* optional: the instance table of a two-level scene (the one given to nnbvh_scene_create_instanced).
+ * Hits inside instance k are then finished on the device as TransformedPrimitive::Intersect does
+ * (cpu/primitive.cpp:112-125): interaction in the instance's space (wo = -ApplyInverse(ray.d)), then
+ * Transform::operator()(const SurfaceInteraction &) with renderFromPrimitive (util/transform.cpp:
+ * 229-261).  Without it such hits get NNBVH_INTERACTION_HOST. */
+int nnbvh_shading_mesh_set_instances(nnbvh_shading_mesh *m, const nnbvh_instance *instances, int n_instances);
 void nnbvh_shading_mesh_destroy(nnbvh_shading_mesh *m);
 
 #define NNBVH_INTERACTION_MISS 0
 #define NNBVH_INTERACTION_TRIANGLE 1 /* all fields valid (Triangle::InteractionFromIntersection) */
-#define NNBVH_INTERACTION_HOST 2     /* hit inside an instance or on a host primitive (or on a primitive
-                                        the mesh has no vertices for): the caller finishes it on the
-                                        host; only prim and status are written, as for a miss */
+#define NNBVH_INTERACTION_HOST 2     /* hit on a host primitive, on a primitive the mesh has no vertices
+                                        for, or inside an instance when no instance table was set: the
+                                        caller finishes it on the host; only prim and status are
+                                        written, as for a miss */
 #define NNBVH_INTERACTION_PATCH 3    /* all fields valid (BilinearPatch::InteractionFromIntersection,
                                         shapes.h:1396-1489) */
 typedef struct nnbvh_interaction {   /* 192 B */

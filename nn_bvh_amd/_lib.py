@@ -49,6 +49,7 @@ EXPORTS = [
     "nnbvh_wavefront_intersect_shadow", "nnbvh_build_create_gpu", "nnbvh_build_gpu_timing",
     "nnbvh_shading_mesh_create", "nnbvh_shading_mesh_destroy", "nnbvh_triangle_interactions_device",
     "nnbvh_triangle_interactions", "nnbvh_scene_create_gpu_build",
+    "nnbvh_shading_mesh_set_instances",
 ]
 
 _lib = None
@@ -122,6 +123,8 @@ def lib():
     L.nnbvh_build_gpu_timing.argtypes = [vp, vp]
     L.nnbvh_shading_mesh_create.restype = vp
     L.nnbvh_shading_mesh_create.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32]
+    L.nnbvh_shading_mesh_set_instances.restype = i32
+    L.nnbvh_shading_mesh_set_instances.argtypes = [vp, vp, i32]
     L.nnbvh_shading_mesh_destroy.restype = None
     L.nnbvh_shading_mesh_destroy.argtypes = [vp]
     L.nnbvh_triangle_interactions.restype = i32

@@ -921,9 +921,26 @@ nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
     return m;
 }
 
+int nnbvh_shading_mesh_set_instances(nnbvh_shading_mesh *m, const nnbvh_instance *instances, int n_instances) {
+    if (!m || n_instances < 0 || (n_instances > 0 && !instances)) {
+        set_error("shading_mesh_set_instances: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    if (m->d.instances) (void)hipFree(m->d.instances);
+    m->d.instances = nullptr;
+    m->d.nInstances = 0;
+    if (n_instances == 0) return NNBVH_OK;
+    if (!upload(&m->d.instances, instances, (size_t)n_instances, "shading mesh: instances")) return NNBVH_ERR_DEVICE;
+    m->d.nInstances = n_instances;
+    return NNBVH_OK;
+}
+
 void nnbvh_shading_mesh_destroy(nnbvh_shading_mesh *m) {
     if (!m) return;
     DeviceGuard guard(m->device);
+    if (m->d.instances) (void)hipFree(m->d.instances);
     void *ptrs[] = {m->d.verts, m->d.triVerts, m->d.patchVerts, m->d.normals, m->d.uvs, m->d.tangents, m->d.faceIndices, m->d.triFlags};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

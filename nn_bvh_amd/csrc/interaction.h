@@ -14,6 +14,8 @@ struct ShadingMeshDevice {  // device pointers of a nnbvh_shading_mesh
     int32_t *faceIndices = nullptr;
     uint8_t *triFlags = nullptr;
     int nTris = 0, nVerts = 0;
+    nnbvh_instance *instances = nullptr;  // optional: hits inside instances are finished on the device too
+    int nInstances = 0;
     unsigned defaultFlags = 0;
 };
 

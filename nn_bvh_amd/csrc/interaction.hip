@@ -95,7 +95,77 @@ struct MeshView {
     const uint8_t *triFlags;
     int nTris;
     unsigned defaultFlags;
+    const nnbvh_instance *instances;
+    int nInstances;
 };
+
+// Transform::operator()(const SurfaceInteraction &) (util/transform.cpp:229-261) with the instance's
+// renderFromPrimitive: what TransformedPrimitive::Intersect does to the hit (cpu/primitive.cpp:122)
+IDEV void xf_vec(const float *m, const float *v, float *out) {  // transform.h:322-326
+    const float x = v[0], y = v[1], z = v[2];
+    for (int i = 0; i < 3; ++i) out[i] = m[4 * i] * x + m[4 * i + 1] * y + m[4 * i + 2] * z;
+}
+IDEV void xf_normal(const float *mi, const float *n, float *out) {  // transform.h:329-334
+    const float x = n[0], y = n[1], z = n[2];
+    for (int i = 0; i < 3; ++i) out[i] = mi[i] * x + mi[4 + i] * y + mi[8 + i] * z;
+}
+IDEV void transform_interaction(const nnbvh_instance &inst, nnbvh_interaction &r) {
+    const float *m = inst.render_from_prim, *mi = inst.prim_from_render;
+    float x[3], ein[3];
+    bool exact = true;
+    for (int k = 0; k < 3; ++k) {
+        x[k] = (r.pi_lo[k] + r.pi_hi[k]) / 2;
+        ein[k] = (r.pi_hi[k] - r.pi_lo[k]) / 2;
+        exact = exact && (r.pi_hi[k] - r.pi_lo[k] == 0);
+    }
+    const float g3 = (3.0f * 0x1p-24f) / (1.0f - 3.0f * 0x1p-24f);
+    float lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) {
+        const float *q = m + 4 * i;
+        const float p = (q[0] * x[0] + q[1] * x[1]) + (q[2] * x[2] + q[3]);
+        const float a = __builtin_fabsf(q[0] * x[0]) + __builtin_fabsf(q[1] * x[1]) + __builtin_fabsf(q[2] * x[2]) +
+                        __builtin_fabsf(q[3]);
+        float e;
+        if (exact) e = g3 * a;
+        else
+            e = (g3 + 1) * (__builtin_fabsf(q[0]) * ein[0] + __builtin_fabsf(q[1]) * ein[1] +
+                            __builtin_fabsf(q[2]) * ein[2]) + g3 * a;
+        if (e == 0) {
+            lo[i] = hi[i] = p;
+        } else {
+            lo[i] = next_down(p + (-e));
+            hi[i] = next_up(p + e);
+        }
+    }
+    for (int k = 0; k < 3; ++k) r.pi_lo[k] = lo[k], r.pi_hi[k] = hi[k];
+    float t[3];
+    xf_normal(mi, r.n, t);
+    F3 n = normalize(F3{t[0], t[1], t[2]});
+    xf_vec(m, r.wo, t);
+    const F3 wo = normalize(F3{t[0], t[1], t[2]});
+    r.wo[0] = wo.x, r.wo[1] = wo.y, r.wo[2] = wo.z;
+    xf_vec(m, r.dpdu, t);
+    r.dpdu[0] = t[0], r.dpdu[1] = t[1], r.dpdu[2] = t[2];
+    xf_vec(m, r.dpdv, t);
+    r.dpdv[0] = t[0], r.dpdv[1] = t[1], r.dpdv[2] = t[2];
+    xf_normal(mi, r.dndu, t);
+    r.dndu[0] = t[0], r.dndu[1] = t[1], r.dndu[2] = t[2];
+    xf_normal(mi, r.dndv, t);
+    r.dndv[0] = t[0], r.dndv[1] = t[1], r.dndv[2] = t[2];
+    xf_normal(mi, r.ns, t);
+    F3 ns = normalize(F3{t[0], t[1], t[2]});
+    xf_vec(m, r.dpdus, t);
+    r.dpdus[0] = t[0], r.dpdus[1] = t[1], r.dpdus[2] = t[2];
+    xf_vec(m, r.dpdvs, t);
+    r.dpdvs[0] = t[0], r.dpdvs[1] = t[1], r.dpdvs[2] = t[2];
+    xf_normal(mi, r.dndus, t);
+    r.dndus[0] = t[0], r.dndus[1] = t[1], r.dndus[2] = t[2];
+    xf_normal(mi, r.dndvs, t);
+    r.dndvs[0] = t[0], r.dndvs[1] = t[1], r.dndvs[2] = t[2];
+    if (dot_n(ns, n) < 0.f) ns = neg(ns);  // shading.n = FaceForward(shading.n, n) (:257)
+    r.n[0] = n.x, r.n[1] = n.y, r.n[2] = n.z;
+    r.ns[0] = ns.x, r.ns[1] = ns.y, r.ns[2] = ns.z;
+}
 
 IDEV F3 lerp3(float t, F3 a, F3 b) {  // (1 - t) * a + t * b: vecmath.h:410-412
     const float s = 1 - t;
@@ -254,7 +324,8 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
         r.status = NNBVH_INTERACTION_MISS;
         if (prim >= 0) {
             r.status = NNBVH_INTERACTION_HOST;
-            if (__float_as_int(h1.w) == 0 && prim < m.nTris) {
+            const int inst = __float_as_int(h1.w);  // 0 top level, k + 1 inside instance k
+            if ((inst == 0 || (inst > 0 && inst <= m.nInstances)) && prim < m.nTris) {
                 if (m.triVerts[3 * (long)prim] >= 0) r.status = NNBVH_INTERACTION_TRIANGLE;
                 else if (m.patchVerts && m.patchVerts[4 * (long)prim] >= 0) r.status = NNBVH_INTERACTION_PATCH;
             }
@@ -275,8 +346,19 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
             wo = {-soa.dx[i], -soa.dy[i], -soa.dz[i]};
             time = soa.time ? soa.time[i] : 0.0f;
         }
+        const int instIdx = __float_as_int(h1.w) - 1;
+        if (instIdx >= 0) {
+            // TransformedPrimitive::Intersect (cpu/primitive.cpp:112-125): the shape sees the ray in the
+            // instance's space, ray.d = renderFromPrimitive.ApplyInverse(r.d) (util/transform.h:401-405)
+            const float *mi = m.instances[instIdx].prim_from_render;
+            const F3 d = neg(wo);
+            const F3 di = {mi[0] * d.x + mi[1] * d.y + mi[2] * d.z, mi[4] * d.x + mi[5] * d.y + mi[6] * d.z,
+                           mi[8] * d.x + mi[9] * d.y + mi[10] * d.z};
+            wo = neg(di);
+        }
         if (r.status == NNBVH_INTERACTION_PATCH) {
             patch_interaction(m, prim, h0.z, h0.w, wo, time, r);
+            if (instIdx >= 0) transform_interaction(m.instances[instIdx], r);
             out[i] = r;
             continue;
         }
@@ -397,6 +479,7 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
         r.dpdvs[0] = sdpdv.x, r.dpdvs[1] = sdpdv.y, r.dpdvs[2] = sdpdv.z;
         r.dndus[0] = dndu.x, r.dndus[1] = dndu.y, r.dndus[2] = dndu.z;
         r.dndvs[0] = dndv.x, r.dndvs[1] = dndv.y, r.dndvs[2] = dndv.z;
+        if (instIdx >= 0) transform_interaction(m.instances[instIdx], r);
         out[i] = r;
     }
 }
@@ -404,7 +487,8 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
 hipError_t launch_triangle_interactions(const ShadingMeshDevice &m, const void *rays, const nnbvh_ray_soa *soa,
                                         const void *hits, int n, const int32_t *nDev, void *out, int maxBlocks,
                                         hipStream_t stream) {
-    MeshView v{m.verts, m.triVerts, m.patchVerts, m.normals, m.uvs, m.tangents, m.faceIndices, m.triFlags, m.nTris, m.defaultFlags};
+    MeshView v{m.verts, m.triVerts, m.patchVerts, m.normals, m.uvs, m.tangents, m.faceIndices, m.triFlags, m.nTris, m.defaultFlags,
+               m.instances, m.nInstances};
     nnbvh_ray_soa s;
     __builtin_memset(&s, 0, sizeof s);
     if (soa) s = *soa;

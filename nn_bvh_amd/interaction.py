@@ -34,6 +34,13 @@ class ShadingMesh:
         if not self._h:
             raise NNBVHError("nnbvh_shading_mesh_create: " + _lib.last_error())
 
+    def set_instances(self, instances):
+        """The scene's instance table (INSTANCE_DTYPE): hits inside instances are then finished on the
+        device (TransformedPrimitive::Intersect's transform of the interaction)."""
+        inst = np.ascontiguousarray(instances, _lib.INSTANCE_DTYPE)
+        check(_lib.lib().nnbvh_shading_mesh_set_instances(self._h, ptr(inst), len(inst)),
+              "nnbvh_shading_mesh_set_instances")
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().nnbvh_shading_mesh_destroy(self._h)

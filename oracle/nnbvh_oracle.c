@@ -1245,3 +1245,65 @@ void orc_patch_interaction_batch(const float *in40, int n, float *out50) {
                               r + 14, r[17], 7 + i, out50 + 50 * (size_t)i);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Transform::operator()(const SurfaceInteraction &) (util/transform.cpp:229-261) for an affine
+ * transform: m / m_inv are the 3x4 render-from-primitive matrix and its inverse (row 3 = 0 0 0 1,
+ * so the homogeneous weight is exactly 1).  What TransformedPrimitive::Intersect applies to a hit
+ * inside an instance (cpu/primitive.cpp:112-125).
+ * in39 / out39: pi low[3] high[3], then n, wo, dpdu, dpdv, dndu, dndv, shading n, dpdu, dpdv, dndu,
+ * dndv (3 floats each). */
+static inline void xf_vec(const float m[12], const float v[3], float out[3]) { /* transform.h:322-326 */
+    for (int i = 0; i < 3; ++i) out[i] = m[4 * i] * v[0] + m[4 * i + 1] * v[1] + m[4 * i + 2] * v[2];
+}
+static inline void xf_normal(const float mi[12], const float n[3], float out[3]) { /* transform.h:329-334 */
+    for (int i = 0; i < 3; ++i) out[i] = mi[i] * n[0] + mi[4 + i] * n[1] + mi[8 + i] * n[2];
+}
+void orc_transform_interaction(const float m[12], const float m_inv[12], const float in39[39], float out39[39]) {
+    /* Point3fi (transform.h:133-176) */
+    float x[3], err_in[3], exact = 1;
+    for (int k = 0; k < 3; ++k) {
+        x[k] = (in39[k] + in39[3 + k]) / 2;         /* Float(Interval) = Midpoint() */
+        err_in[k] = (in39[3 + k] - in39[k]) / 2;    /* Error() = Width() / 2 */
+        if (in39[3 + k] - in39[k] != 0) exact = 0;
+    }
+    const float g3 = orc_gamma(3);
+    for (int i = 0; i < 3; ++i) {
+        const float *r = m + 4 * i;
+        const float p = (r[0] * x[0] + r[1] * x[1]) + (r[2] * x[2] + r[3]);
+        const float a = fabsf(r[0] * x[0]) + fabsf(r[1] * x[1]) + fabsf(r[2] * x[2]) + fabsf(r[3]);
+        float e;
+        if (exact) e = g3 * a;
+        else e = (g3 + 1) * (fabsf(r[0]) * err_in[0] + fabsf(r[1]) * err_in[1] + fabsf(r[2]) * err_in[2]) + g3 * a;
+        orc_ivl iv = ivl_from_value_and_error(p, e);
+        out39[i] = iv.lo;
+        out39[3 + i] = iv.hi;
+    }
+    float t[3], n[3], ns[3];
+    xf_normal(m_inv, in39 + 6, t);
+    orc_normalize(t, n);                         /* ret.n = Normalize(t(si.n)) */
+    xf_vec(m, in39 + 9, t);
+    orc_normalize(t, out39 + 9);                 /* ret.wo */
+    xf_vec(m, in39 + 12, out39 + 12);            /* dpdu */
+    xf_vec(m, in39 + 15, out39 + 15);            /* dpdv */
+    xf_normal(m_inv, in39 + 18, out39 + 18);     /* dndu */
+    xf_normal(m_inv, in39 + 21, out39 + 21);     /* dndv */
+    xf_normal(m_inv, in39 + 24, t);
+    orc_normalize(t, ns);                        /* shading.n */
+    xf_vec(m, in39 + 27, out39 + 27);
+    xf_vec(m, in39 + 30, out39 + 30);
+    xf_normal(m_inv, in39 + 33, out39 + 33);
+    xf_normal(m_inv, in39 + 36, out39 + 36);
+    if (orc_dot_n(ns, n) < 0.f)                  /* shading.n = FaceForward(shading.n, n) (:257) */
+        for (int k = 0; k < 3; ++k) ns[k] = -ns[k];
+    memcpy(out39 + 6, n, 12);
+    memcpy(out39 + 24, ns, 12);
+}
+/* records as oracle/ref_interaction.cpp's "xf" mode: 72 floats in (4x4 m, 4x4 mInv, 39 fields, pad), 40 out */
+void orc_transform_interaction_batch(const float *in72, int n, float *out40) {
+    for (int i = 0; i < n; ++i) {
+        const float *r = in72 + 72 * (size_t)i;
+        orc_transform_interaction(r, r + 16, r + 32, out40 + 40 * (size_t)i);
+        out40[40 * (size_t)i + 39] = 0;
+    }
+}

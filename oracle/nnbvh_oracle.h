@@ -129,6 +129,11 @@ int orc_patch_interaction(const float p12[12], const float *uv8, const float *n1
                           float out[50]);
 void orc_patch_interaction_batch(const float *in40, int n, float *out50);
 
+/* Transform::operator()(const SurfaceInteraction &) (util/transform.cpp:229-261), affine 3x4 m / m_inv;
+ * fields: pi low[3] high[3], n, wo, dpdu, dpdv, dndu, dndv, shading n, dpdu, dpdv, dndu, dndv */
+void orc_transform_interaction(const float m[12], const float m_inv[12], const float in39[39], float out39[39]);
+void orc_transform_interaction_batch(const float *in72, int n, float *out40);
+
 /* brute force closest hit over all prims in index order (no BVH): a second,
  * tree-independent check of t for the traversal restatement. */
 void orc_brute_closest(const orc_prim *prims, int n_prims, const float *verts,

@@ -14,7 +14,13 @@
 //            uv00 uv10 uv01 uv11 [19:27], n00 n10 n01 n11 [27:39], pad
 //   out.bin: n records of 50 float32: the 38 below, pi low[3] / high[3], geometric dndu[3] dndv[3]
 //
-// usage: ref_interaction [tri|blp] <in.bin> <out.bin>      (mode defaults to tri)
+// With mode "xf": Transform::operator()(const SurfaceInteraction &) (util/transform.cpp:229-261), what
+// TransformedPrimitive::Intersect applies to a hit inside an instance (cpu/primitive.cpp:112-125).
+//   in.bin : int32 n, then n records of 72 float32: m[16] mInv[16] (row-major), pi low[3] high[3],
+//            n, wo, dpdu, dpdv, dndu, dndv, shading n, dpdu, dpdv, dndu, dndv (3 each), pad
+//   out.bin: n records of 40 float32: pi low[3] high[3] and the same eleven vectors, pad
+//
+// usage: ref_interaction [tri|blp|xf] <in.bin> <out.bin>      (mode defaults to tri)
 //   in.bin : int32 n, then n records of 36 float32:
 //            p0[3] p1[3] p2[3]  b0 b1 b2  wo[3]  time  flags  uv0[2] uv1[2] uv2[2]  n0[3] n1[3] n2[3]  s0? -> see below
 //            flags bit 0: mesh has uv, bit 1: mesh has n, bit 2: mesh has s, bit 3: reverseOrientation
@@ -86,9 +92,53 @@ static int run_patches(FILE *fi, FILE *fo) {
     return 0;
 }
 
+static int run_transform(FILE *fi, FILE *fo) {
+    constexpr int kInX = 72, kOutX = 40;
+    int32_t n = 0;
+    if (std::fread(&n, 4, 1, fi) != 1) return 4;
+    std::vector<float> in((size_t)n * kInX);
+    if (std::fread(in.data(), 4, in.size(), fi) != in.size()) return 4;
+    for (int i = 0; i < n; ++i) {
+        const float *r = &in[(size_t)i * kInX];
+        SquareMatrix<4> m, mInv;
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                m[a][b] = r[4 * a + b];
+                mInv[a][b] = r[16 + 4 * a + b];
+            }
+        Transform xf(m, mInv);
+        SurfaceInteraction si;
+        si.pi = Point3fi(Interval(r[32], r[35]), Interval(r[33], r[36]), Interval(r[34], r[37]));
+        auto V = [&](int at) { return Vector3f(r[at], r[at + 1], r[at + 2]); };
+        auto N = [&](int at) { return Normal3f(r[at], r[at + 1], r[at + 2]); };
+        si.n = N(38), si.wo = V(41), si.dpdu = V(44), si.dpdv = V(47), si.dndu = N(50), si.dndv = N(53);
+        si.shading.n = N(56), si.shading.dpdu = V(59), si.shading.dpdv = V(62);
+        si.shading.dndu = N(65), si.shading.dndv = N(68);
+        SurfaceInteraction t = xf(si);
+        float out[kOutX] = {t.pi.x.LowerBound(), t.pi.y.LowerBound(), t.pi.z.LowerBound(),
+                            t.pi.x.UpperBound(), t.pi.y.UpperBound(), t.pi.z.UpperBound(),
+                            t.n.x, t.n.y, t.n.z, t.wo.x, t.wo.y, t.wo.z, t.dpdu.x, t.dpdu.y, t.dpdu.z,
+                            t.dpdv.x, t.dpdv.y, t.dpdv.z, t.dndu.x, t.dndu.y, t.dndu.z, t.dndv.x, t.dndv.y, t.dndv.z,
+                            t.shading.n.x, t.shading.n.y, t.shading.n.z,
+                            t.shading.dpdu.x, t.shading.dpdu.y, t.shading.dpdu.z,
+                            t.shading.dpdv.x, t.shading.dpdv.y, t.shading.dpdv.z,
+                            t.shading.dndu.x, t.shading.dndu.y, t.shading.dndu.z,
+                            t.shading.dndv.x, t.shading.dndv.y, t.shading.dndv.z, 0.f};
+        std::fwrite(out, 4, kOutX, fo);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc != 3 && argc != 4) return 2;
     const bool patches = argc == 4 && std::string(argv[1]) == "blp";
+    if (argc == 4 && std::string(argv[1]) == "xf") {
+        FILE *fi = std::fopen(argv[2], "rb"), *fo = std::fopen(argv[3], "wb");
+        if (!fi || !fo) return 3;
+        int rc = run_transform(fi, fo);
+        std::fclose(fo);
+        return rc;
+    }
     FILE *fi = std::fopen(argv[argc - 2], "rb");
     FILE *fo = std::fopen(argv[argc - 1], "wb");
     if (!fi || !fo) return 3;

@@ -112,3 +112,41 @@ def patch_cases(n, seed):
     rec[k, 9:12] = rec[k, 3:6] + np.float64([0.7, -0.7, 0]) * scale[k]
     rec[:, 27:39] = nrm.reshape(n, 12)
     return rec
+
+
+def transform_cases(n, seed):
+    """Transform::operator()(SurfaceInteraction) inputs (oracle/ref_interaction.cpp "xf" layout): m[16],
+    mInv[16] (affine, row-major), pi low/high, and eleven vectors; rigid, scaled, mirrored transforms."""
+    rng = np.random.default_rng(seed)
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                  2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).reshape(n, 3, 3)
+    S = 10.0 ** rng.uniform(-1.5, 1.5, size=(n, 3)) * rng.choice([-1, 1], size=(n, 3), p=[0.15, 0.85])
+    kind = rng.integers(0, 6, n)
+    R[kind == 0] = np.eye(3)
+    S[kind == 1] = 1.0
+    M = np.zeros((n, 4, 4))
+    M[:, :3, :3] = R * S[:, None, :]
+    M[:, :3, 3] = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-1, 3, size=(n, 1))
+    M[kind == 2, :3, 3] = 0
+    M[:, 3, 3] = 1
+    Mi = np.linalg.inv(M)
+    rec = np.zeros((n, 72), np.float32)
+    rec[:, 0:16] = M.reshape(n, 16)
+    rec[:, 16:32] = Mi.reshape(n, 16)
+    p = (rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-2, 3, size=(n, 1))).astype(np.float32)
+    err = (np.abs(p) * 10.0 ** rng.uniform(-7, -4, size=(n, 3))).astype(np.float32)
+    err[kind == 3] = 0                                 # exact points (IsExact)
+    rec[:, 32:35] = p - err
+    rec[:, 35:38] = p + err
+    vecs = rng.normal(size=(n, 11, 3)) * 10.0 ** rng.uniform(-2, 2, size=(n, 11, 1))
+    nrm = vecs[:, 0] / np.linalg.norm(vecs[:, 0], axis=1, keepdims=True)
+    vecs[:, 0] = nrm
+    sn = nrm + rng.normal(size=(n, 3)) * 0.3
+    sn[kind == 4] *= -1                                # shading normal on the other side: FaceForward flips it
+    vecs[:, 6] = sn / np.linalg.norm(sn, axis=1, keepdims=True)
+    rec[:, 38:71] = vecs.reshape(n, 33)
+    return rec

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.path.join(ROOT, "oracle", "_ref", "ref_interaction")
 sys.path.insert(0, HERE)
-from interaction_cases import cases, patch_cases  # noqa: E402
+from interaction_cases import cases, patch_cases, transform_cases  # noqa: E402
 
 
 def run_ref(rec, mode="tri"):
@@ -24,7 +24,7 @@ def run_ref(rec, mode="tri"):
             f.write(np.int32(len(rec)).tobytes())
             f.write(np.ascontiguousarray(rec, np.float32).tobytes())
         subprocess.run([REF, mode, fi, fo], check=True)
-        return np.fromfile(fo, dtype=np.uint32).reshape(len(rec), 44 if mode == "tri" else 50)
+        return np.fromfile(fo, dtype=np.uint32).reshape(len(rec), {"tri": 44, "blp": 50, "xf": 40}[mode])
 
 
 if __name__ == "__main__":
@@ -36,3 +36,7 @@ if __name__ == "__main__":
     out = run_ref(rec, "blp")
     np.savez_compressed(os.path.join(HERE, "blp_interaction.npz"), inputs=rec, outputs=out)
     print("blp_interaction.npz:", rec.shape, out.shape)
+    rec = transform_cases(3072, 20240609)
+    out = run_ref(rec, "xf")
+    np.savez_compressed(os.path.join(HERE, "xf_interaction.npz"), inputs=rec, outputs=out)
+    print("xf_interaction.npz:", rec.shape, out.shape)

@@ -196,3 +196,11 @@ def patch_branches(reset=False):
         for k in range(8):
             arr[k] = 0
     return vals
+
+
+def transform_interaction_batch(records72):
+    """orc_transform_interaction_batch on oracle/ref_interaction.cpp "xf" records -> float32 [n, 40]."""
+    rec = np.ascontiguousarray(records72, np.float32).reshape(-1, 72)
+    out = np.zeros((len(rec), 40), np.float32)
+    lib().orc_transform_interaction_batch(_p(rec), ctypes.c_int(len(rec)), _p(out))
+    return out

@@ -17,7 +17,7 @@ import oracle_binding as ob
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
-from interaction_cases import cases, patch_cases  # noqa: E402
+from interaction_cases import cases, patch_cases, transform_cases  # noqa: E402
 
 GOLDEN = os.path.join(HERE, "golden", "tri_interaction.npz")
 REF = os.path.join(HERE, "..", "oracle", "_ref", "ref_interaction")
@@ -104,6 +104,117 @@ def test_gpu_patch_interactions_match_oracle_on_reference_vectors():
     assert_records_equal(got, exp, np.arange(n), "patch golden inputs")
     for name, sl in (("dndu", slice(44, 47)), ("dndv", slice(47, 50))):
         assert np.array_equal(got[name].view(np.uint32), exp[:, sl].view(np.uint32)), name
+    mesh.close()
+
+
+def test_oracle_interaction_transform_matches_reference_vectors_bit_exact():
+    """Transform::operator()(const SurfaceInteraction &) (util/transform.cpp:229-261)."""
+    g = np.load(os.path.join(HERE, "golden", "xf_interaction.npz"))
+    out = ob.transform_interaction_batch(g["inputs"])
+    assert np.array_equal(out.view(np.uint32), g["outputs"])
+    # both branches of the error propagation and the FaceForward flip occur in the vectors
+    rec = g["inputs"]
+    assert ((rec[:, 35:38] - rec[:, 32:35]) == 0).all(1).any() and ((rec[:, 35:38] - rec[:, 32:35]) != 0).all(1).any()
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.isdir("/root/reference")),
+                    reason="compiled reference harness only exists in the build container")
+def test_oracle_interaction_transform_equals_reference_live():
+    rec = transform_cases(20000, 6)
+    with tempfile.TemporaryDirectory() as td:
+        fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fi, "wb") as f:
+            f.write(np.int32(len(rec)).tobytes())
+            f.write(rec.tobytes())
+        subprocess.run([REF, "xf", fi, fo], check=True)
+        ref = np.fromfile(fo, dtype=np.uint32).reshape(len(rec), 40)
+    assert np.array_equal(ob.transform_interaction_batch(rec).view(np.uint32), ref)
+
+
+@pytest.mark.gpu
+def test_gpu_interactions_inside_instances():
+    """Hits inside instances: interaction in the instance's space, then renderFromPrimitive applied
+    (TransformedPrimitive::Intersect, cpu/primitive.cpp:112-125), all on the device."""
+    from nn_bvh_amd import BVHAggregate, scene
+    from nn_bvh_amd.interaction import ShadingMesh
+    from test_instancing import two_level_scene
+    verts, nodes, prims, instances, n_top, _ = two_level_scene(3, 50)
+    prims = prims.copy()
+    prims["id"] = np.arange(len(prims))  # ids index the shading mesh, so they must be unique
+    n_ids = len(prims)
+    tri_vertices = np.full((n_ids, 3), -1, np.int32)
+    patch_vertices = np.full((n_ids, 4), -1, np.int32)
+    tri_vertices[prims["id"][prims["kind"] == 0]] = prims["v"][prims["kind"] == 0][:, :3]
+    patch_vertices[prims["id"][prims["kind"] == 1]] = prims["v"][prims["kind"] == 1]
+    rng = np.random.default_rng(8)
+    normals = rng.normal(size=(len(verts), 3)).astype(np.float32)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    mesh = ShadingMesh(verts, tri_vertices, normals=normals, patch_vertices=patch_vertices)
+    agg = BVHAggregate.from_tree(nodes, prims, verts, instances=instances, n_top_nodes=n_top)
+    lo = np.array([-30, -30, -30.0])
+    rays = scene.random_rays(60000, lo, -lo, 9)
+    rays["time"] = rng.random(len(rays)).astype(np.float32)
+    hits = agg.Intersect(rays)
+    inside = hits["instance"] > 0
+    assert inside.sum() > 1000
+    got = mesh.interactions(rays, hits)
+    assert (got["status"][inside] == 2).all(), "without the instance table such hits are left to the host"
+    mesh.set_instances(instances)
+    got = mesh.interactions(rays, hits)
+    for kind, status in ((0, 1), (1, 3)):
+        is_kind = (tri_vertices if kind == 0 else patch_vertices)[np.maximum(hits["prim"], 0), 0] >= 0
+        rows = np.nonzero(inside & (hits["prim"] >= 0) & is_kind)[0]
+        assert len(rows) > (200 if kind == 0 else 20)
+        assert (got["status"][rows] == status).all()
+        inst = instances[hits["instance"][rows] - 1]
+        mi = inst["prim_from_render"].reshape(-1, 3, 4)
+        d = rays["d"][rows]
+        d_in = np.stack([(mi[:, i, 0] * d[:, 0] + mi[:, i, 1] * d[:, 1]) + mi[:, i, 2] * d[:, 2] for i in range(3)], 1)
+        if kind == 0:
+            rec = np.zeros((len(rows), 45), np.float32)
+            tv = tri_vertices[hits["prim"][rows]]
+            rec[:, 0:9] = verts[tv].reshape(-1, 9)
+            rec[:, 9], rec[:, 10], rec[:, 11] = hits["b0"][rows], hits["b1"][rows], hits["b2"][rows]
+            rec[:, 12:15] = -d_in
+            rec[:, 18] = rays["time"][rows]
+            rec[:, 19] = 2
+            rec[:, 26:35] = normals[tv].reshape(-1, 9)
+            local = ob.triangle_interaction_batch(rec)
+            gdn = np.zeros((len(rows), 6), np.float32)
+        else:
+            rec = np.zeros((len(rows), 40), np.float32)
+            pv = patch_vertices[hits["prim"][rows]]
+            rec[:, 0:12] = verts[pv].reshape(-1, 12)
+            rec[:, 12], rec[:, 13] = hits["b0"][rows], hits["b1"][rows]
+            rec[:, 14:17] = -d_in
+            rec[:, 17] = rays["time"][rows]
+            rec[:, 18] = 2
+            rec[:, 27:39] = normals[pv].reshape(-1, 12)
+            local = ob.patch_interaction_batch(rec)
+            gdn = local[:, 44:50]
+        xf = np.zeros((len(rows), 72), np.float32)
+        for half, name in ((0, "render_from_prim"), (16, "prim_from_render")):
+            m44 = np.zeros((len(rows), 4, 4), np.float32)
+            m44[:, :3, :] = inst[name].reshape(-1, 3, 4)
+            m44[:, 3, 3] = 1
+            xf[:, half:half + 16] = m44.reshape(-1, 16)
+        xf[:, 32:38] = local[:, 38:44]                       # pi low / high
+        xf[:, 38:41], xf[:, 41:44] = local[:, 11:14], local[:, 8:11]   # n, wo
+        xf[:, 44:50] = local[:, 14:20]                       # dpdu dpdv
+        xf[:, 50:56] = gdn                                   # geometric dndu dndv
+        xf[:, 56:71] = local[:, 20:35]                       # shading n dpdu dpdv dndu dndv
+        exp = ob.transform_interaction_batch(xf)
+        g = got[rows]
+        for name, sl in (("pi_lo", slice(0, 3)), ("pi_hi", slice(3, 6)), ("n", slice(6, 9)), ("wo", slice(9, 12)),
+                         ("dpdu", slice(12, 15)), ("dpdv", slice(15, 18)), ("dndu", slice(18, 21)),
+                         ("dndv", slice(21, 24)), ("ns", slice(24, 27)), ("dpdus", slice(27, 30)),
+                         ("dpdvs", slice(30, 33)), ("dndus", slice(33, 36)), ("dndvs", slice(36, 39))):
+            a = np.ascontiguousarray(g[name]).view(np.uint32)
+            b = np.ascontiguousarray(exp[:, sl]).view(np.uint32)
+            bad = np.nonzero((a != b).any(1))[0]
+            assert len(bad) == 0, f"kind {kind}: {name} differs on {len(bad)} of {len(rows)} records"
+        assert np.array_equal(g["uv"].view(np.uint32), np.ascontiguousarray(local[:, 6:8]).view(np.uint32))
+    agg.close()
     mesh.close()
 
 
