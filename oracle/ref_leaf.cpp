@@ -17,18 +17,22 @@
 //                                     applies, src/pbrt/cpu/primitive.cpp:112-131)
 //   pbrt::Transform::operator()(const Bounds3f &)     (src/pbrt/util/transform.cpp:134-139: the
 //                                     bounds TransformedPrimitive::Bounds() reports, cpu/primitive.h:91)
-// usage: ref_leaf <tri|blp|slab|xfray|xfbounds> <in.bin> <out.bin>
+//   pbrt::EncodeMorton3 + Bounds3f::Offset            (src/pbrt/util/math.h:99-119, util/vecmath.h:1322-1331:
+//                                     the Morton code buildHLBVH gives a primitive, cpu/aggregates.cpp:398-408)
+// usage: ref_leaf <tri|blp|slab|xfray|xfbounds|morton> <in.bin> <out.bin>
 //   in.bin : int32 n, then n records of float32
 //              tri : o[3] d[3] tmax p0[3] p1[3] p2[3]              (16 floats)
 //              blp : o[3] d[3] tmax p00[3] p10[3] p01[3] p11[3]    (19 floats)
 //              slab: o[3] d[3] tmax pmin[3] pmax[3]                (13 floats)
 //              xfray: o[3] d[3] tmax m[16] mInv[16] (row-major)     (39 floats)
 //              xfbounds: m[16] (row-major) pmin[3] pmax[3]          (22 floats)
+//              morton: centroid-bounds pmin[3] pmax[3], centroid[3]  (9 floats)
 //   out.bin: n records: tri  -> int32 hit, float b0 b1 b2 t
 //                       blp  -> int32 hit, float u v t
 //                       slab -> int32 hit
 //                       xfray-> int32 1, float o'[3] d'[3] tmax'
 //                       xfbounds-> int32 1, float pmin'[3] pmax'[3]
+//                       morton-> int32 code
 #include <pbrt/pbrt.h>
 #include <pbrt/ray.h>
 #include <pbrt/shapes.h>
@@ -50,8 +54,9 @@ int main(int argc, char **argv) {
         return 2;
     }
     int mode = !std::strcmp(argv[1], "tri") ? 0 : !std::strcmp(argv[1], "blp") ? 1
-               : !std::strcmp(argv[1], "slab") ? 2 : !std::strcmp(argv[1], "xfray") ? 3 : 4;
-    const int stride[5] = {16, 19, 13, 39, 22};
+               : !std::strcmp(argv[1], "slab") ? 2 : !std::strcmp(argv[1], "xfray") ? 3
+               : !std::strcmp(argv[1], "xfbounds") ? 4 : 5;
+    const int stride[6] = {16, 19, 13, 39, 22, 9};
     FILE *fi = std::fopen(argv[2], "rb");
     FILE *fo = std::fopen(argv[3], "wb");
     if (!fi || !fo) return 3;
@@ -95,6 +100,14 @@ int main(int argc, char **argv) {
             out[0] = tr.o.x, out[1] = tr.o.y, out[2] = tr.o.z;
             out[3] = tr.d.x, out[4] = tr.d.y, out[5] = tr.d.z;
             out[6] = t;
+        } else if (mode == 5) {
+            // exactly the statements of buildHLBVH (cpu/aggregates.cpp:398-408)
+            Bounds3f bounds(P(r), P(r + 3));
+            constexpr int mortonBits = 10;
+            constexpr int mortonScale = 1 << mortonBits;
+            Vector3f centroidOffset = bounds.Offset(P(r + 6));
+            Vector3f offset = centroidOffset * mortonScale;
+            hit = (int32_t)EncodeMorton3(offset.x, offset.y, offset.z);
         } else if (mode == 4) {
             SquareMatrix<4> m;
             for (int a = 0; a < 4; ++a)

@@ -233,6 +233,23 @@ def xfbounds_cases(rng):
     return np.concatenate([m, lo, lo + ext], 1).astype(np.float32)
 
 
+def morton_scene(rng):
+    """A triangle soup (partly clustered, partly coincident) + what buildHLBVH feeds EncodeMorton3:
+    the bounds of the primitives' centroids and each centroid, in float32 as the builder computes them
+    (BVHPrimitive::Centroid() = .5f * pMin + .5f * pMax, cpu/aggregates.h)."""
+    n = 6000
+    c = rng.uniform(-10, 10, size=(n, 1, 3))
+    c[4000:5000] = rng.uniform(-0.01, 0.01, size=(1000, 1, 3)) + 3.0   # a tight cluster
+    c[5000:5200] = c[5000]                                            # coincident centroids
+    v = (c + rng.uniform(-0.6, 0.6, size=(n, 3, 3))).astype(np.float32)
+    v[5000:5200] = v[5000]
+    mn, mx = v.min(1), v.max(1)
+    cen = (np.float32(0.5) * mn + np.float32(0.5) * mx).astype(np.float32)
+    cb = np.concatenate([cen.min(0), cen.max(0)]).astype(np.float32)
+    rec = np.concatenate([np.tile(cb, (n, 1)), cen], 1).astype(np.float32)
+    return v.reshape(-1, 3), rec
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/ref_leaf missing: run `make -C oracle ref` in the build container")
@@ -245,6 +262,18 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"leaf_{mode}.npz"), inputs=recs, hit=hit,
                             out_bits=bits)
         print(f"{mode}: {len(recs)} cases, {int(hit.sum())} hits")
+    verts, rec = morton_scene(rng)
+    codes, _ = run_ref("morton", rec, 0)
+    raw = None
+    with tempfile.TemporaryDirectory() as td:  # codes are full int32 values, not flags: re-read them as such
+        fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fi, "wb") as f:
+            f.write(np.int32(len(rec)).tobytes())
+            f.write(rec.tobytes())
+        subprocess.run([REF, "morton", fi, fo], check=True)
+        raw = np.fromfile(fo, dtype=np.uint32)
+    np.savez_compressed(os.path.join(OUT, "hlbvh_morton.npz"), verts=verts, inputs=rec, codes=raw)
+    print(f"morton: {len(rec)} codes, {len(np.unique(raw))} distinct")
 
 
 if __name__ == "__main__":

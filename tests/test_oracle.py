@@ -49,6 +49,22 @@ def test_transform_bounds_match_reference_vectors_bit_exact():
         assert (got.view(np.uint32) == exp).all(), i
 
 
+def test_hlbvh_leaf_order_follows_the_reference_morton_codes(nnbvh_lib):
+    """buildHLBVH's per-primitive Morton codes (Bounds3::Offset + EncodeMorton3, aggregates.cpp:398-408)
+    computed by the reference binary for a 6 000-triangle soup; HLBVH's leaf-ordered primitive table
+    is the primitives in stable-sorted code order (the 5 x 6-bit LSD radix sort is stable), which pins
+    the host builder's codes, its sort, and — through tests/test_gpu_build.py — the device builder's."""
+    from nn_bvh_amd import build_tree, make_prims
+    g = np.load(os.path.join(GOLD, "hlbvh_morton.npz"))
+    verts, codes = g["verts"], g["codes"]
+    n = len(codes)
+    prims = make_prims(np.arange(3 * n, dtype=np.int32).reshape(n, 3))
+    tree = build_tree(prims, verts, 4, "hlbvh")
+    assert np.array_equal(tree.ordered_prims["id"], np.argsort(codes, kind="stable"))
+    assert len(np.unique(codes)) > 4000 and (np.bincount(np.unique(codes, return_inverse=True)[1]) >= 200).any()
+    assert (codes < (1 << 30)).all()
+
+
 def test_golden_vectors_reach_the_rare_branches():
     """The vectors must include exact-zero edge functions (the fp64 fallback), degenerate
     triangles and zero direction components, or the pin would not cover those branches."""
