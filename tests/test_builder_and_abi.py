@@ -136,3 +136,36 @@ def test_scene_create_validates_tree_and_fails_loudly_without_gpu(nnbvh_lib):
     assert nnbvh_lib.nnbvh_scene_bounds(None, None) == 1
     nnbvh_lib.nnbvh_scene_destroy(None)
     nnbvh_lib.nnbvh_build_destroy(None)
+
+
+def test_shading_mesh_validates_indices_before_touching_a_device(nnbvh_lib):
+    """nnbvh_shading_mesh_create range-checks every vertex index on the host (the interaction kernel
+    gathers with them); without a GPU the valid case then fails loudly on the device step."""
+    from nn_bvh_amd import NNBVHError
+    from nn_bvh_amd.interaction import ShadingMesh
+    verts = np.zeros((6, 3), np.float32)
+    with pytest.raises(NNBVHError, match="vertex index out of range"):
+        ShadingMesh(verts, np.array([[0, 1, 2], [3, 4, 9]], np.int32))
+    with pytest.raises(NNBVHError, match="patch vertex index out of range"):
+        ShadingMesh(verts, np.array([[0, 1, 2], [-1, 0, 0]], np.int32),
+                    patch_vertices=np.array([[-1, 0, 0, 0], [0, 1, 2, 6]], np.int32))
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(NNBVHError):
+            ShadingMesh(verts, np.array([[0, 1, 2]], np.int32))
+
+
+def test_gpu_build_entry_points_fail_loudly_without_a_gpu(nnbvh_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from nn_bvh_amd import BVHAggregate, NNBVHError, build_tree_gpu, make_prims
+    verts = np.random.default_rng(0).random((30, 3)).astype(np.float32)
+    prims = make_prims(np.arange(30, dtype=np.int32).reshape(10, 3))
+    for method in ("sah", "hlbvh"):
+        with pytest.raises(NNBVHError):
+            build_tree_gpu(prims, verts, split_method=method)
+        with pytest.raises(NNBVHError):
+            BVHAggregate.build_on_device(prims, verts, split_method=method)
+    with pytest.raises(NNBVHError, match="sah.*hlbvh"):
+        build_tree_gpu(prims, verts, split_method="middle")
