@@ -195,6 +195,70 @@ int nnbvh_device_count(void) {
     return n;
 }
 
+// a scene object around arrays baked on the device (bvh_bake.hip)
+static nnbvh_scene *scene_from_baked(const BakedScene &b, int depth, int device) {
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) {
+        (void)hipFree(b.d_wide);
+        (void)hipFree(b.d_prims);
+        return nullptr;
+    }
+    auto *s = new nnbvh_scene;
+    s->device = device;
+    s->n_cus = prop.multiProcessorCount;
+    s->n_interior = b.n_interior;
+    s->n_slots = b.n_slots;
+    s->depth = depth;
+    std::memcpy(s->bounds, b.bounds, sizeof b.bounds);
+    s->root_ref = b.root_ref;
+    s->instanced = 0;
+    s->has_host_prims = b.has_host_prims;
+    s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
+    s->d_wide = (float4 *)b.d_wide;
+    s->d_prims = (float4 *)b.d_prims;
+    s->device_bytes = (size_t)std::max(b.n_interior, 1) * sizeof(WideNode) +
+                      std::max<size_t>((size_t)b.n_slots, 1) * 16;
+    if (hipMalloc((void **)&s->d_stats, 16 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(s->d_stats, 0, 16 * sizeof(unsigned long long));
+    if (const char *e = std::getenv("NNBVH_STACK_WINDOW")) nnbvh_scene_set_option(s, "stack_window", atoi(e));
+    if (const char *e = std::getenv("NNBVH_BLOCKS_PER_CU")) nnbvh_scene_set_option(s, "blocks_per_cu", atoi(e));
+    if (const char *e = std::getenv("NNBVH_XCD_QUEUES")) nnbvh_scene_set_option(s, "xcd_queues", atoi(e));
+    if (const char *e = std::getenv("NNBVH_REFILL_WEIGHT")) nnbvh_scene_set_option(s, "refill_weight", atoi(e));
+    if (const char *e = std::getenv("NNBVH_PRIM_WEIGHT")) nnbvh_scene_set_option(s, "prim_weight", atoi(e));
+    return s;
+}
+
+// Single-level scenes: the validated tree is uploaded as it is and baked on the device (the same
+// arrays the host code below produces for two-level scenes, without the host pass over every node
+// and primitive).
+static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
+                                             int n_prims, const float *verts, int n_verts, int depth, int device) {
+    int n_dev = nnbvh_device_count();
+    if (n_dev <= 0 || device < 0 || device >= n_dev) {
+        set_error("scene_create: no usable HIP device (this library has no CPU fallback)");
+        return nullptr;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return nullptr;
+    void *d_nodes = nullptr, *d_prims = nullptr, *d_verts = nullptr;
+    const size_t nb = (size_t)n_nodes * sizeof(nnbvh_linear_node), pbytes = (size_t)n_prims * sizeof(nnbvh_prim),
+                 vb = (size_t)n_verts * 12;
+    BakedScene b;
+    std::string err;
+    bool ok = hip_ok(hipMalloc(&d_nodes, nb), "hipMalloc(tree)") && hip_ok(hipMalloc(&d_prims, pbytes), "hipMalloc(primitives)") &&
+              hip_ok(hipMalloc(&d_verts, vb), "hipMalloc(vertices)") &&
+              hip_ok(hipMemcpy(d_nodes, nodes, nb, hipMemcpyHostToDevice), "hipMemcpy(tree)") &&
+              hip_ok(hipMemcpy(d_prims, prims, pbytes, hipMemcpyHostToDevice), "hipMemcpy(primitives)") &&
+              hip_ok(hipMemcpy(d_verts, verts, vb, hipMemcpyHostToDevice), "hipMemcpy(vertices)");
+    if (ok && !bake_on_device(d_nodes, n_nodes, d_prims, n_prims, d_verts, device, &b, &err)) {
+        set_error(err);
+        ok = false;
+    }
+    for (void *p : {d_nodes, d_prims, d_verts})
+        if (p) (void)hipFree(p);
+    return ok ? scene_from_baked(b, depth, device) : nullptr;
+}
+
 static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, int n_top_nodes,
                                  const nnbvh_prim *prims, int n_prims, const float *verts,
                                  int n_verts, const nnbvh_instance *instances, int n_instances,
@@ -264,6 +328,8 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
         set_error("scene_create: primitive stream exceeds 2^31 slots");
         return nullptr;
     }
+    if (n_instances == 0)
+        return create_scene_device_bake(nodes, n_nodes, prims, n_prims, verts, n_verts, depth, device);
     // interior record numbers (global over all trees) and node refs
     std::vector<int> ord((size_t)n_nodes, -1);
     int n_interior = 0;
@@ -415,28 +481,8 @@ nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, 
         set_error(err);
         return nullptr;
     }
-    hipDeviceProp_t prop;
-    if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) {
-        (void)hipFree(b.d_wide);
-        (void)hipFree(b.d_prims);
-        return nullptr;
-    }
-    auto *s = new nnbvh_scene;
-    s->device = device;
-    s->n_cus = prop.multiProcessorCount;
-    s->n_interior = b.n_interior;
-    s->n_slots = b.n_slots;
-    s->depth = r.depth;
-    std::memcpy(s->bounds, b.bounds, sizeof b.bounds);
-    s->root_ref = b.root_ref;
-    s->instanced = 0;
-    s->has_host_prims = b.has_host_prims;
-    s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
-    s->d_wide = (float4 *)b.d_wide;
-    s->d_prims = (float4 *)b.d_prims;
-    s->device_bytes = (size_t)std::max(b.n_interior, 1) * sizeof(WideNode) + (size_t)b.n_slots * 16;
-    if (hipMalloc((void **)&s->d_stats, 16 * sizeof(unsigned long long)) == hipSuccess)
-        (void)hipMemset(s->d_stats, 0, 16 * sizeof(unsigned long long));
+    nnbvh_scene *s = scene_from_baked(b, r.depth, device);
+    if (!s) return nullptr;
     s->build_ms[0] = r.ms[0] + r.ms[1] + r.ms[2] + r.ms[3] + r.ms[4];
     return s;
 }
