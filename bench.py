@@ -7,7 +7,12 @@ HBM, one launch per ray class:
     closest-hit  over spp x 1000x1400 primary rays   (BVHAggregate::Intersect)
     closest-hit  over the diffuse-bounce rays of those hits
     any-hit      over the shadow rays of those hits  (BVHAggregate::IntersectP, tMax = 1-1e-4)
-value = rays traced by all ranks / wall time of K steps (max over ranks).
+    RecordShadowRayResult -> L per pixel sample, UpdateFilm / RGBFilm::AddSample -> the film's
+    4 doubles per pixel (film.h:239-255, 302-307)
+value = rays traced by all ranks / wall time of K steps (max over ranks).  Consecutive steps
+trace different samples: --sample-sets (default 4) distinct sets of spp samples are resident and
+used round-robin.  BASELINE's "1024 spp" is extrapolated from these passes as SURVEY.md §8d
+prescribes (>= 64 M rays per class are timed; 1.4 G x depth rays are not traced).
 
 Why 8 spp per launch: a launch's time is T(n) = ramp/drain + n / steady-state rate, and the
 drain is the dependent-load chain of the longest ray in the batch (crown: V up to ~600 nodes,
@@ -17,27 +22,37 @@ with 288 GB of HBM the natural MI355X design is fewer, larger launches (8 spp of
 film = 11.2 M rays = 0.7 GB of ray + hit records).  --spp 1 reproduces the 1 M-ray regime.
 
 Multi-GPU: the BVH is replicated; each rank owns an interleaved set of 16x16
-image tiles (Morton-ordered ray chunks), traces only its tiles' rays — no data-path
-collective inside the timed steps — and the per-tile results are all-gathered once after the
-timed region (reported separately as allgather_ms).  Per-GPU work is fixed as N grows
-(weak scaling): with --gpus N the job is N samples per pixel and rank r traces its tiles of
-every sample, i.e. --spp films' worth of rays per GPU.
+image tiles (Morton-ordered ray chunks), traces only its tiles' rays and accumulates only its
+tiles' film pixels — no data-path collective inside the timed steps — and when the pass is
+complete the per-tile film accumulators are all-gathered once (RCCL over xGMI; reported as
+film_allgather_ms; the all-gather of the 32-B hit records is kept as a second figure).
+Per-GPU work is fixed as N grows (weak scaling): with --gpus N the job is N x spp samples per
+pixel and rank r traces its tiles of every sample, i.e. spp films' worth of rays per GPU.
+
+`python bench.py --gpus N` with N > 1 starts its own ranks (torch.distributed.run, one per
+GPU) before anything touches the GPU; launched under torchrun it uses the ranks it was given.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--scene crown] [--no-cpu-baseline]
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §HBM)
+SHADER_GHZ = 2.4       # MI355X peak engine clock
+N_SIMD = 1024          # 256 CUs x 4 SIMD-32
+# BASELINE.md §2: the reference's own CPU path, 8 threads, crown — primary closest / bounce closest /
+# bounce any-hit.  Measured in the survey container (Xeon 2.1 GHz, 8 vCPU), NOT on this box.
+REFERENCE_8T_MRAYS = {"primary_closest": 5.2, "bounce_closest": 3.1, "bounce_any": 4.2}
 
 
 def log(*a):
@@ -56,13 +71,15 @@ def host_cores():
     return max(1, n)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="crown")
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel traced per step")
+    ap.add_argument("--sample-sets", type=int, default=4,
+                    help="distinct sets of --spp samples kept resident and traced round-robin")
     ap.add_argument("--tree", default="sah", choices=["sah", "hlbvh", "middle", "equal", "nn", "sah_gpu", "hlbvh_gpu"],
                     help="tree builder: pbrt split methods (host), nn = greedy-SAH top levels of "
                          "machine_learning/nn_BVH.py finished by SAH and baked (BASELINE config 5), "
@@ -77,14 +94,93 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="rays per class timed on the host cores for cpu_baseline")
     ap.add_argument("--cpu-passes", type=int, default=5)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n_gpus):
+    """Start one rank per GPU as child processes and return their exit code.  Called before torch
+    or HIP is imported: this parent never touches the GPU (a process that has must not exec)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log(f"[bench] --gpus {n_gpus} without a launcher: starting {n_gpus} ranks: {' '.join(cmd[1:8])} ...")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """NNBVH_BENCH_DRYRUN=1: rendezvous only (gloo, no GPU) — the CPU test of the launch path."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        total = 1.0
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": total, "steps": args.steps,
+                          "warmup": args.warmup}), flush=True)
+    return 0
+
+
+def profile_counters():
+    """VALU-issue figures of the closest-hit kernel from the newest committed rocprofv3 PMC summary
+    (profiles/r*_final*/summary.json; collected as MI355X_MICROARCH.md prescribes, separate --pmc
+    passes of this same command).  None if no summary is present."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final*", "summary.json")))
+    for path in reversed(paths):
+        try:
+            summ = json.load(open(path))
+            name = next(k for k in summ["counters_per_launch_mean"] if k.startswith("trace_kernel<0"))
+            c = summ["counters_per_launch_mean"][name]
+            ks = next(k for k in summ["kernel_stats"] if "trace_kernel<0" in k["Name"])
+            cycles = float(ks["AverageNs"]) * SHADER_GHZ
+            return {
+                "source": os.path.relpath(path, ROOT),
+                "spp": summ.get("spp"),
+                "kernel": name,
+                "avg_launch_ms": round(float(ks["AverageNs"]) / 1e6, 4),
+                # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (tools/halfwave_probe.hip)
+                "frac": round(c["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cycles), 4),
+                "lanes_per_valu": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"], 2),
+                "salu_per_valu": round(c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"], 3),
+                "wait_frac_of_wave_cycles": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+                "hbm_bytes_per_launch": round(c["TCC_EA0_RDREQ_sum"] * 128 - c.get("TCC_EA0_RDREQ_32B_sum", 0) * 96
+                                              - c.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 + c["WRITE_SIZE"] * 1024),
+            }
+        except (OSError, ValueError, KeyError, StopIteration):
+            continue
+    return None
+
+
+def main():
+    args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+        sys.exit(2)
+    if os.environ.get("NNBVH_BENCH_DRYRUN") == "1":
+        sys.exit(dry_run(args, rank, world))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -102,9 +198,18 @@ def main():
         else:
             dist.init_process_group(backend)
     coll_dev = "cuda" if backend == "nccl" else "cpu"
+    cdev = torch.device("cuda", local_rank)
 
     from nn_bvh_amd import BVHAggregate, build_tree, make_prims, scene, shard
-    from nn_bvh_amd._lib import HIT_DTYPE
+    from nn_bvh_amd._lib import HIT_DTYPE, check, lib
+    from nn_bvh_amd.film import Film
+
+    def max_over_ranks(x):
+        if world == 1 or x is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     t0 = time.time()
     verts, tris, source = scene.load_scene(args.scene)
@@ -133,66 +238,154 @@ def main():
             f"window {agg.info['stack_window']}")
 
     # ---- ray batches (synthetic, seeded).  The job is `world * spp` samples per pixel of the
-    # film; rank r traces its interleaved 16x16 tiles of every sample, i.e. spp films' worth of
-    # rays per GPU whatever N is (weak scaling).
+    # film per step; rank r traces its interleaved 16x16 tiles of every sample, i.e. spp films'
+    # worth of rays per GPU whatever N is (weak scaling).  --sample-sets distinct sets of samples
+    # are resident; step i traces set i mod sets.
     cam_name = args.scene if args.scene in scene.CAMERAS else "crown"
-    xres = scene.CAMERAS[cam_name][4]
+    xres, yres = scene.CAMERAS[cam_name][4], scene.CAMERAS[cam_name][5]
     _, px, py = scene.camera_rays(cam_name, seed=1, sample=0, return_pixels=True)
-    mine = shard.shard_indices(px, py, xres, world, rank)
-    primary = np.concatenate([scene.camera_rays(cam_name, seed=1, sample=s_idx, subset=mine)
-                              for s_idx in range(world * args.spp)])
-    shard_bytes = world * args.spp * shard.shard_counts(px, py, xres, world) * 32  # hit bytes/rank
-    n_primary = len(primary)
+    index_lists = [shard.shard_indices(px, py, xres, world, r) for r in range(world)]
+    mine = index_lists[rank]
+    n_slots = len(mine)                     # pixel slots of this rank = film pixels it owns
+    passes = world * args.spp               # samples per pixel and step
+    shard_bytes = passes * shard.shard_counts(px, py, xres, world) * 32  # hit bytes/rank
+    stream = torch.cuda.current_stream().cuda_stream
 
     def dev(a):
-        return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
+        return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(cdev)
 
-    stream = torch.cuda.current_stream().cuda_stream
-    d_primary = dev(primary)
-    d_hits = torch.empty(n_primary * 32, dtype=torch.uint8, device="cuda")
-    agg.intersect_device(d_primary.data_ptr(), d_hits.data_ptr(), n_primary, stream)
-    torch.cuda.synchronize()
-    hits = d_hits.cpu().numpy().view(HIT_DTYPE)
-    bounce = scene.bounce_rays(primary, hits, verts, tris, seed=2 + rank)
     lo, hi = verts.min(0), verts.max(0)
-    if args.scene == "crown":  # towards the scene's six area-light quads (crown.pbrt:26-102)
-        shadow = scene.shadow_rays_to_quads(primary, hits, verts, tris, scene.CROWN_LIGHT_QUADS,
-                                            seed=3 + rank)
-    else:
-        shadow = scene.shadow_rays(primary, hits, verts, tris, lo + (hi - lo) * [0.3, 0.9, 0.3],
-                                   lo + (hi - lo) * [0.7, 1.0, 0.7], seed=3 + rank)
-    d_bounce, d_shadow = dev(bounce), dev(shadow)
-    d_bhits = torch.empty(len(bounce) * 32, dtype=torch.uint8, device="cuda")
-    d_occ = torch.empty(len(shadow), dtype=torch.uint8, device="cuda")
-    rays_per_step = n_primary + len(bounce) + len(shadow)
-
-    def step():
+    t_gen = time.time()
+    sets = []
+    for k in range(max(1, args.sample_sets)):
+        primary = np.concatenate([scene.camera_rays(cam_name, seed=1, sample=k * passes + s_idx, subset=mine)
+                                  for s_idx in range(passes)])
+        n_primary = len(primary)
+        d_primary = dev(primary)
+        d_hits = torch.empty(n_primary * 32, dtype=torch.uint8, device=cdev)
         agg.intersect_device(d_primary.data_ptr(), d_hits.data_ptr(), n_primary, stream)
-        agg.intersect_device(d_bounce.data_ptr(), d_bhits.data_ptr(), len(bounce), stream)
-        agg.intersect_p_device(d_shadow.data_ptr(), d_occ.data_ptr(), len(shadow), stream=stream)
+        torch.cuda.synchronize()
+        hits = d_hits.cpu().numpy().view(HIT_DTYPE)
+        bounce = scene.bounce_rays(primary, hits, verts, tris, seed=[2, rank, k])
+        if args.scene == "crown":  # towards the scene's six area-light quads (crown.pbrt:26-102)
+            shadow = scene.shadow_rays_to_quads(primary, hits, verts, tris, scene.CROWN_LIGHT_QUADS,
+                                                seed=[3, rank, k])
+        else:
+            shadow = scene.shadow_rays(primary, hits, verts, tris, lo + (hi - lo) * [0.3, 0.9, 0.3],
+                                       lo + (hi - lo) * [0.7, 1.0, 0.7], seed=[3, rank, k])
+        gen = torch.Generator(device=cdev).manual_seed(100 + 10 * rank + k)
+        st = {
+            "primary": primary if k == 0 else None, "bounce": bounce if k == 0 else None,
+            "shadow": shadow if k == 0 else None, "hits": hits if k == 0 else None,
+            "n_primary": n_primary, "n_bounce": len(bounce), "n_shadow": len(shadow),
+            "d_primary": d_primary, "d_hits": d_hits, "d_bounce": dev(bounce), "d_shadow": dev(shadow),
+            "d_bhits": torch.empty(len(bounce) * 32, dtype=torch.uint8, device=cdev),
+            "d_occ": torch.empty(len(shadow), dtype=torch.uint8, device=cdev),
+            # ShadowRayWorkItem payload (workitems.soa:77-83): Ld, r_u, r_l per shadow ray, the pixel
+            # sample it belongs to; PixelSampleState::L per pixel sample (SampledSpectrum = 4 floats)
+            "d_pix": torch.from_numpy(np.nonzero(hits["prim"] >= 0)[0].astype(np.int32)).to(cdev),
+            "d_Ld": torch.rand((len(shadow), 4), generator=gen, device=cdev) * 2.0,
+            "d_ru": torch.rand((len(shadow), 4), generator=gen, device=cdev) + 0.5,
+            "d_rl": torch.rand((len(shadow), 4), generator=gen, device=cdev) + 0.5,
+            "d_L": torch.zeros((n_primary, 4), dtype=torch.float32, device=cdev),
+            "d_w": torch.rand(n_primary, generator=gen, device=cdev) + 0.5,  # filterWeight per sample
+        }
+        sets.append(st)
+    s0 = sets[0]
+    rays_per_step = s0["n_primary"] + s0["n_bounce"] + s0["n_shadow"]
+    if rank == 0:
+        log(f"[bench] {len(sets)} sample sets x {passes} samples generated in {time.time() - t_gen:.1f}s; "
+            f"{rays_per_step} rays/step/GPU")
+
+    # the film of the whole image; this rank accumulates the pixels of its tiles
+    film = Film(xres, yres, device=local_rank)
+    d_px = torch.from_numpy(px[mine].astype(np.int32)).to(cdev)
+    d_py = torch.from_numpy(py[mine].astype(np.int32)).to(cdev)
+    L = lib()
+
+    def vp(t):
+        import ctypes
+        return ctypes.c_void_p(t.data_ptr())
+
+    def film_stage(st):
+        import ctypes
+        st["d_L"].zero_()
+        check(L.nnbvh_wavefront_record_shadow_device(vp(st["d_occ"]), st["n_shadow"], None, vp(st["d_Ld"]),
+                                                     vp(st["d_ru"]), vp(st["d_rl"]), vp(st["d_pix"]),
+                                                     vp(st["d_L"]), st["n_primary"], local_rank,
+                                                     ctypes.c_void_p(stream)), "record_shadow")
+        # sensor RGB = the first three of L's four wavelength samples (the spectral sensor model,
+        # film.h:95-100, is the caller's); slot i of every pass is pixel mine[i]
+        film.add_samples_device(d_px, d_py, st["d_L"], st["d_w"], n_slots, passes, rgb_stride=4, stream=stream)
+
+    def trace_stage(st):
+        agg.intersect_device(st["d_primary"].data_ptr(), st["d_hits"].data_ptr(), st["n_primary"], stream)
+        agg.intersect_device(st["d_bounce"].data_ptr(), st["d_bhits"].data_ptr(), st["n_bounce"], stream)
+        agg.intersect_p_device(st["d_shadow"].data_ptr(), st["d_occ"].data_ptr(), st["n_shadow"], stream=stream)
+
+    def step(i):
+        st = sets[i % len(sets)]
+        trace_stage(st)
+        film_stage(st)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    film.clear(stream)
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     barrier()
     elapsed = time.perf_counter() - t_start
+    elapsed = max_over_ranks(elapsed)
+    # every set has its own bounce / shadow counts: rays actually traced in the K steps
+    def rays_of(st):
+        return st["n_primary"] + st["n_bounce"] + st["n_shadow"]
+    rays_timed = float(sum(rays_of(sets[i % len(sets)]) for i in range(args.steps)))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([rays_per_step], dtype=torch.float64, device=coll_dev)
+        tot = torch.tensor([rays_timed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_rays_per_step = float(tot.item())
-    else:
-        total_rays_per_step = float(rays_per_step)
+        rays_timed = float(tot.item())
+
+    # ---- the film all-gather that ends the pass (RCCL over xGMI under nccl): every rank packs the
+    # accumulators of its tiles, one all_gather_into_tensor, the others' tiles are unpacked
+    film_allgather_ms = film_bytes = None
+    allgather_ms = None
+    if world > 1:
+        if backend == "nccl":
+            d_lists = [torch.from_numpy((py[ix].astype(np.int64) * xres + px[ix]).astype(np.int32)).to(cdev)
+                       for ix in index_lists]
+            film.all_gather_tiles(d_lists, rank, stream)  # warm-up (communicator setup), idempotent
+            barrier()
+            t1 = time.perf_counter()
+            film_bytes = film.all_gather_tiles(d_lists, rank, stream)
+            barrier()
+            film_allgather_ms = max_over_ranks((time.perf_counter() - t1) * 1e3)
+        else:  # rehearsal over gloo: the same protocol on a host copy of the accumulators
+            pix = torch.from_numpy(film.read())
+            lin = [torch.from_numpy(py[ix].astype(np.int64) * xres + px[ix]) for ix in index_lists]
+            barrier()
+            t1 = time.perf_counter()
+            shard.all_gather_film(pix, lin, rank)
+            barrier()
+            film_allgather_ms = max_over_ranks((time.perf_counter() - t1) * 1e3)
+            film_bytes = max(len(ix) for ix in index_lists) * 32
+        # second figure: the 32-B hit records of one step
+        g_src = s0["d_hits"] if backend == "nccl" else s0["d_hits"].cpu()
+        shard.all_gather_records(g_src, shard_bytes)
+        barrier()
+        t1 = time.perf_counter()
+        gathered = shard.all_gather_records(g_src, shard_bytes)
+        barrier()
+        allgather_ms = max_over_ranks((time.perf_counter() - t1) * 1e3)
+        assert sum(g.numel() for g in gathered) == int(shard_bytes.sum())
+    weight_sum = float(film.read()[:, 3].sum()) if rank == 0 else 0.0
 
     # ---- per-kernel timing with events on the launch stream (dominant kernel = closest-hit) ----
     def time_kernel(fn, reps):
@@ -206,13 +399,18 @@ def main():
         return float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     reps = max(3, min(args.steps, 10))
-    ms_primary = time_kernel(lambda: agg.intersect_device(d_primary.data_ptr(), d_hits.data_ptr(),
+    n_primary, n_bounce, n_shadow = s0["n_primary"], s0["n_bounce"], s0["n_shadow"]
+    ms_primary = time_kernel(lambda: agg.intersect_device(s0["d_primary"].data_ptr(), s0["d_hits"].data_ptr(),
                                                           n_primary, stream), reps)
-    ms_bounce = time_kernel(lambda: agg.intersect_device(d_bounce.data_ptr(), d_bhits.data_ptr(),
-                                                         len(bounce), stream), reps)
-    ms_shadow = time_kernel(lambda: agg.intersect_p_device(d_shadow.data_ptr(), d_occ.data_ptr(),
-                                                           len(shadow), stream=stream), reps)
-    bhits = d_bhits.cpu().numpy().view(HIT_DTYPE)
+    ms_bounce = time_kernel(lambda: agg.intersect_device(s0["d_bounce"].data_ptr(), s0["d_bhits"].data_ptr(),
+                                                         n_bounce, stream), reps)
+    ms_shadow = time_kernel(lambda: agg.intersect_p_device(s0["d_shadow"].data_ptr(), s0["d_occ"].data_ptr(),
+                                                           n_shadow, stream=stream), reps)
+    ms_film = time_kernel(lambda: film_stage(s0), reps)
+    hits = s0["hits"]
+    primary, bounce, shadow = s0["primary"], s0["bounce"], s0["shadow"]
+    bhits = s0["d_bhits"].cpu().numpy().view(HIT_DTYPE)
+
     # algorithmic bytes: 32 in + 32*V + 48*T + 32 out per closest-hit ray
     def alg_bytes(h):
         return 64.0 * len(h) + 32.0 * h["nodes_visited"].sum(dtype=np.int64) + \
@@ -223,12 +421,10 @@ def main():
 
     # ---- the same step through nnbvh_trace_batches_device: the three batches run concurrently
     # on the library's internal streams, so each launch's drain overlaps the others' work.
-    # Reported next to `value` (which stays the one-launch-at-a-time figure the per-kernel
-    # roofline and the rocprofv3 kernel averages refer to).
     def step_overlapped():
-        agg.trace_batches_device([("closest", d_primary.data_ptr(), n_primary, d_hits.data_ptr()),
-                                  ("closest", d_bounce.data_ptr(), len(bounce), d_bhits.data_ptr()),
-                                  ("any", d_shadow.data_ptr(), len(shadow), d_occ.data_ptr())], stream)
+        agg.trace_batches_device([("closest", s0["d_primary"].data_ptr(), n_primary, s0["d_hits"].data_ptr()),
+                                  ("closest", s0["d_bounce"].data_ptr(), n_bounce, s0["d_bhits"].data_ptr()),
+                                  ("any", s0["d_shadow"].data_ptr(), n_shadow, s0["d_occ"].data_ptr())], stream)
 
     overlapped_s = None
     if args.overlapped:
@@ -238,30 +434,22 @@ def main():
         for _ in range(args.steps):
             step_overlapped()
         barrier()
-        overlapped_s = time.perf_counter() - t1
-    if world > 1 and overlapped_s is not None:
-        t = torch.tensor([overlapped_s], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        overlapped_s = float(t.item())
+        overlapped_s = max_over_ranks(time.perf_counter() - t1)
 
     # ---- the same step through the wavefront-queue entry points (SOA ray queues with
     # device-side sizes in, index queues and pixel radiance out): opt-in, reported next to `value`
-    wavefront_s = None
+    wavefront_s = wavefront_intr_s = None
     if args.wavefront:
         from nn_bvh_amd.wavefront import RayQueue, WavefrontAggregate, WorkQueue
         from nn_bvh_amd._lib import CLOSEST_QUEUES
-        cdev = torch.device("cuda", local_rank)
         wf = WavefrontAggregate(agg, np.zeros(len(tris), np.uint8))
         q_primary, q_bounce = RayQueue.from_records(primary, cdev), RayQueue.from_records(bounce, cdev)
         q_shadow = RayQueue.from_records(shadow, cdev, shadow=True)
         outq = {k: WorkQueue(n_primary, cdev) for k in CLOSEST_QUEUES}
-        rng = np.random.default_rng(11)
-        spec = [torch.from_numpy(rng.random((len(shadow), 4), np.float32) + np.float32(0.5)).to(cdev)
-                for _ in range(3)]
-        pix = torch.arange(len(shadow), dtype=torch.int32, device=cdev)
-        L = torch.zeros((len(shadow), 4), dtype=torch.float32, device=cdev)
-        d_hits2 = d_hits.view(-1, 32)
-        d_bhits2 = d_bhits.view(-1, 32)
+        pix = torch.arange(n_shadow, dtype=torch.int32, device=cdev)
+        Lw = torch.zeros((n_shadow, 4), dtype=torch.float32, device=cdev)
+        d_hits2 = s0["d_hits"].view(-1, 32)
+        d_bhits2 = s0["d_bhits"].view(-1, 32)
 
         def step_wavefront():
             for q in outq.values():
@@ -269,8 +457,8 @@ def main():
             wf.IntersectClosest(n_primary, q_primary, hits=d_hits2, **outq)
             for q in outq.values():
                 q.Reset()
-            wf.IntersectClosest(len(bounce), q_bounce, hits=d_bhits2, **outq)
-            wf.IntersectShadow(len(shadow), q_shadow, spec[0], spec[1], spec[2], pix, L)
+            wf.IntersectClosest(n_bounce, q_bounce, hits=d_bhits2, **outq)
+            wf.IntersectShadow(n_shadow, q_shadow, s0["d_Ld"], s0["d_ru"], s0["d_rl"], pix, Lw)
 
         step_wavefront()
         barrier()
@@ -278,7 +466,7 @@ def main():
         for _ in range(args.steps):
             step_wavefront()
         barrier()
-        wavefront_s = time.perf_counter() - t1
+        wavefront_s = max_over_ranks(time.perf_counter() - t1)
         # ... and with the hit -> SurfaceInteraction post-pass of both closest-hit stages
         # (Triangle::InteractionFromIntersection, which the reference's Intersect runs per hit)
         from nn_bvh_amd.interaction import ShadingMesh
@@ -289,7 +477,7 @@ def main():
             step_wavefront()
             smesh.interactions_device(d_hits2.data_ptr(), n_primary, d_intr.data_ptr(), ray_queue=q_primary,
                                       stream=stream)
-            smesh.interactions_device(d_bhits2.data_ptr(), len(bounce), d_intr.data_ptr(), ray_queue=q_bounce,
+            smesh.interactions_device(d_bhits2.data_ptr(), n_bounce, d_intr.data_ptr(), ray_queue=q_bounce,
                                       stream=stream)
 
         step_wavefront_intr()
@@ -298,38 +486,20 @@ def main():
         for _ in range(args.steps):
             step_wavefront_intr()
         barrier()
-        wavefront_intr_s = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([wavefront_s], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wavefront_s = float(t.item())
+        wavefront_intr_s = max_over_ranks(time.perf_counter() - t1)
 
-    allgather_ms = None
-    if world > 1:
-        # film-sample hand-off after the pass: one RCCL all-gather of the per-tile hit records
-        g_src = d_hits if backend == "nccl" else d_hits.cpu()
-        shard.all_gather_records(g_src, shard_bytes)  # warm-up (communicator setup)
-        barrier()
-        t1 = time.perf_counter()
-        gathered = shard.all_gather_records(g_src, shard_bytes)
-        barrier()
-        allgather_ms = (time.perf_counter() - t1) * 1e3
-        assert sum(g.numel() for g in gathered) == int(shard_bytes.sum())
-
-    # HBM-side traffic of the closest-hit kernel per launch, from the committed rocprofv3 PMC
-    # passes of this same command (profiles/; collected and corrected as MI355X_MICROARCH.md
-    # §HBM prescribes).  Only quoted when the profile was taken at the same --spp.
-    traffic = None
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-        if tr.get("spp") == args.spp and args.scene == "crown" and world == 1:
-            traffic = round(float(tr["bytes"]))
-    except (OSError, ValueError, KeyError):
-        pass
+    # What binds the kernel, from the committed rocprofv3 PMC passes of this same command
+    # (profiles/; collected and corrected as MI355X_MICROARCH.md §HBM prescribes).  Only quoted when
+    # the profile was taken at the same --spp on crown at N=1.
+    prof = profile_counters()
+    if prof is not None and not (prof.get("spp") in (None, args.spp) and args.scene == "crown" and world == 1):
+        prof = None
+    traffic = prof["hbm_bytes_per_launch"] if prof else None
 
     result = None
     if rank == 0:
-        value = total_rays_per_step * args.steps / elapsed / 1e6
+        value = rays_timed / elapsed / 1e6
+        total_spp = world * args.spp
         result = {
             "metric": "Mray/s (closest-hit + any-hit)",
             "value": round(value, 2),
@@ -344,25 +514,43 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.scene}: {args.spp} spp wavefront pass per step, primary+bounce "
-                            f"closest-hit and shadow any-hit, {rays_per_step} rays/step/GPU",
+                "workload": f"{args.scene}, {xres}x{yres}: one wavefront pass of {total_spp} spp per step "
+                            f"({args.spp} spp per GPU-film) — primary + diffuse-bounce closest-hit, shadow "
+                            f"any-hit towards the light quads, RecordShadowRayResult + RGBFilm::AddSample into a "
+                            f"4-doubles-per-pixel film; {args.steps} steps rotating over {len(sets)} distinct "
+                            f"sample sets; BASELINE's 1024 spp = {1024 // max(1, total_spp)} such passes, "
+                            f"extrapolated per SURVEY §8d (>= 64 M rays per class timed), not traced",
                 "spp_per_step": args.spp,
+                "sample_sets": len(sets),
                 "geometry": source,
                 "tree": args.tree,
                 "triangles": int(len(tris)),
                 "nodes": int(len(tree.nodes)),
                 "rays_primary": int(n_primary),
-                "rays_bounce": int(len(bounce)),
-                "rays_shadow": int(len(shadow)),
-                "parallelism": f"tile-sharded x{world}, BVH replicated",
+                "rays_bounce": int(n_bounce),
+                "rays_shadow": int(n_shadow),
+                "rays_per_step_per_gpu": int(rays_per_step),
+                "parallelism": f"tile-sharded x{world}, BVH replicated, film all-gather after the pass",
             },
             "per_class_mrays": {
                 "primary_closest": round(n_primary / ms_primary / 1e3, 2),
-                "bounce_closest": round(len(bounce) / ms_bounce / 1e3, 2),
-                "shadow_any": round(len(shadow) / ms_shadow / 1e3, 2),
+                "bounce_closest": round(n_bounce / ms_bounce / 1e3, 2),
+                "shadow_any": round(n_shadow / ms_shadow / 1e3, 2),
+            },
+            "film": {
+                "pixels": xres * yres, "bytes_per_pixel": 32,
+                "stage_ms_per_step": round(ms_film, 4),
+                "weight_sum": weight_sum,
+                "how": "RecordShadowRayResult -> L, then UpdateFilm/RGBFilm::AddSample of every pixel "
+                       "sample in sample order (inside the timed step)",
             },
             "roofline": {
+                # the prescribed SURVEY §8d figure ("alg_hbm"): algorithmic bytes 64 + 32 V + 48 T per
+                # ray over the kernel's time against the HBM peak.  It prices every node re-read that
+                # L1/L2 serve, so it is NOT a physical bound and may exceed 1; `binding` names the
+                # limiter the counters show and `valu_issue` / `hbm_physical` quantify it.
                 "bound": "hbm",
+                "label": "alg_hbm",
                 "kernel": "trace_kernel<closest>",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
@@ -374,24 +562,45 @@ def main():
                 "mean_nodes_visited": round(float(hits["nodes_visited"].mean()), 2),
                 "mean_prim_tests": round(float(hits["prim_tests"].mean()), 2),
                 "avg_launch_ms": round(ms_closest / 2, 4),
+                "binding": "valu_issue",
+                "valu_issue": None if prof is None else {
+                    "frac": prof["frac"], "lanes_per_valu": prof["lanes_per_valu"],
+                    "salu_per_valu": prof["salu_per_valu"],
+                    "wait_frac_of_wave_cycles": prof["wait_frac_of_wave_cycles"],
+                    "how": "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x launch cycles at 2.4 GHz); lanes = "
+                           "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)",
+                    "profile_avg_launch_ms": prof["avg_launch_ms"], "source": prof["source"],
+                },
+                "hbm_physical": None if prof is None else {
+                    "achieved": round(prof["hbm_bytes_per_launch"] / (prof["avg_launch_ms"] * 1e-3) / 1e9, 1),
+                    "unit": "GB/s",
+                    "frac": round(prof["hbm_bytes_per_launch"] / (prof["avg_launch_ms"] * 1e-3) / 1e9
+                                  / HBM_PEAK_GBS, 4),
+                },
             },
         }
         if overlapped_s is not None:
             result["overlapped_batches"] = {
-                "value": round(total_rays_per_step * args.steps / overlapped_s / 1e6, 2),
+                "value": round(rays_per_step * world * args.steps / overlapped_s / 1e6, 2),
                 "unit": "Mray/s",
                 "ms_per_step": round(overlapped_s / args.steps * 1e3, 4),
-                "how": "same step as one nnbvh_trace_batches_device call (3 batches concurrent)",
+                "how": "the three traces of sample set 0 as one nnbvh_trace_batches_device call (concurrent)",
             }
         if wavefront_s is not None:
             result["wavefront_queues"] = {
-                "value": round(total_rays_per_step * args.steps / wavefront_s / 1e6, 2),
+                "value": round(rays_per_step * world * args.steps / wavefront_s / 1e6, 2),
                 "unit": "Mray/s",
                 "ms_per_step": round(wavefront_s / args.steps * 1e3, 4),
                 "how": "same step through nnbvh_wavefront_intersect_closest/_shadow: SOA queues in, "
                        "6 index queues + pixel radiance out, queue resets included",
                 "with_surface_interactions_ms_per_step": round(wavefront_intr_s / args.steps * 1e3, 4),
             }
+        if film_allgather_ms is not None:
+            result["film_allgather_ms"] = round(film_allgather_ms, 3)
+            result["film_allgather_bytes_per_rank"] = int(film_bytes)
+            result["film_allgather_backend"] = "rccl" if backend == "nccl" else backend + " (rehearsal, host copy)"
+            result["ms_per_step_incl_film_allgather"] = round(
+                (elapsed * 1e3 + film_allgather_ms) / args.steps, 4)
         if allgather_ms is not None:
             result["allgather_ms"] = round(allgather_ms, 3)
 
@@ -401,9 +610,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_binding as ob
         cores = host_cores()
-        n = min(args.cpu_sample, n_primary, len(bounce), len(shadow))
-        sel = np.sort(np.random.default_rng(0).choice(min(n_primary, len(bounce), len(shadow)), n,
-                                                      replace=False))
+        n = min(args.cpu_sample, n_primary, n_bounce, n_shadow)
+        sel = np.sort(np.random.default_rng(0).choice(min(n_primary, n_bounce, n_shadow), n, replace=False))
         batches = (primary[sel], bounce[sel], shadow[sel])
 
         def cpu_pass():
@@ -421,7 +629,7 @@ def main():
         cpu_s = float(np.median(times))
         # the checker also checks: the sample must agree with what the GPU produced
         same = (c1.tobytes() == hits[sel].tobytes() and c2.tobytes() == bhits[sel].tobytes()
-                and (o3 == d_occ.cpu().numpy()[sel]).all())
+                and (o3 == s0["d_occ"].cpu().numpy()[sel]).all())
         result["cpu_baseline"] = {
             "value": round(3 * n / cpu_s / 1e6, 3),
             "unit": "Mray/s",
@@ -431,9 +639,13 @@ def main():
                       f"oracle/nnbvh_oracle.c on {cores} threads, median of {args.cpu_passes} "
                       f"passes of {cpu_s:.2f}s",
             "matches_gpu": bool(same),
+            "reference_8t_mrays": dict(REFERENCE_8T_MRAYS,
+                                       note="the reference's own compiled CPU path, 8 threads, crown "
+                                            "(BASELINE.md §2): survey container, not this box"),
         }
     if rank == 0:
         print(json.dumps(result), flush=True)
+    film.close()
     agg.close()
     if world > 1:
         dist.destroy_process_group()

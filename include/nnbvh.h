@@ -267,6 +267,46 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
                                      const float *d_r_l, const int32_t *d_pixel_index, float *d_L,
                                      int64_t n_pixels, uint8_t *d_occluded, void *stream);
 
+/* RecordShadowRayResult (wavefront/intersect.h:32-47) for a shadow batch that was traced with
+ * nnbvh_intersect_any_device: the bookkeeping half of nnbvh_wavefront_intersect_shadow on its own. */
+int nnbvh_wavefront_record_shadow_device(const uint8_t *d_occluded, int32_t max_rays, const int32_t *d_size,
+                                         const float *d_Ld, const float *d_r_u, const float *d_r_l,
+                                         const int32_t *d_pixel_index, float *d_L, int64_t n_pixels,
+                                         int device, void *stream);
+
+/* ---- film: RGBFilm's pixel accumulators on the device ------------------------------------------
+ * RGBFilm::Pixel (film.h:302-307: double rgbSum[3], double weightSum; 32 B per pixel, row-major over
+ * the pixel bounds) and RGBFilm::AddSample (film.h:239-255) as UpdateFilm calls it (wavefront/
+ * film.cpp:13-40).  The spectral conversion sensor->ToSensorRGB(L, lambda) (film.h:95-100) stays with
+ * the caller's sensor model: samples arrive as sensor RGB.  In a tile-sharded render every rank owns
+ * the pixels of its tiles; pack / unpack move an index list of pixels between the film and a
+ * contiguous buffer, which is what the RCCL all-gather of the per-tile film samples carries. */
+typedef struct nnbvh_film nnbvh_film;
+/* pixel bounds [x0, x1) x [y0, y1) (Film::PixelBounds); max_component_value = RGBFilm's clamp
+ * ("maxcomponentvalue", default Infinity).  Pixels start at zero.  NULL + nnbvh_last_error(). */
+nnbvh_film *nnbvh_film_create(int32_t x0, int32_t y0, int32_t x1, int32_t y1, float max_component_value,
+                              int device);
+void nnbvh_film_destroy(nnbvh_film *f);
+int nnbvh_film_clear(nnbvh_film *f, void *stream);
+/* Adds n_passes samples to each of n_per_pass pixel slots: slot i is pixel (d_px[i], d_py[i]) (slots
+ * outside the bounds are skipped, wavefront/film.cpp:18-19; the slots' pixels must be distinct, as
+ * the reference's pixelIndex is within a stage), sample (pass, i) is d_rgb[rgb_stride * (pass *
+ * n_per_pass + i) + 0..2] with filter weight d_weight[pass * n_per_pass + i] (NULL = 1).  A slot's
+ * passes are added in order, so the sums equal the reference's sample loop bit for bit.
+ * n_per_pass is clamped to *d_size when d_size != NULL. */
+int nnbvh_film_add_samples_device(nnbvh_film *f, const int32_t *d_px, const int32_t *d_py,
+                                  const float *d_rgb, int32_t rgb_stride, const float *d_weight,
+                                  int32_t n_per_pass, int32_t n_passes, const int32_t *d_size,
+                                  void *stream);
+/* the accumulators themselves: *d_pixels = double[4 * *n_pixels] on the film's device */
+int nnbvh_film_pixels_device(nnbvh_film *f, void **d_pixels, int64_t *n_pixels);
+int nnbvh_film_read(nnbvh_film *f, double *out); /* synchronous copy to double[4 * n_pixels] */
+/* d_index: n linear pixel indices ((y - y0) * width + (x - x0)); buffer: 4 doubles per index */
+int nnbvh_film_pack_pixels_device(nnbvh_film *f, const int32_t *d_index, int64_t n, void *d_out,
+                                  void *stream);
+int nnbvh_film_unpack_pixels_device(nnbvh_film *f, const int32_t *d_index, int64_t n, const void *d_in,
+                                    void *stream);
+
 /* ---- hit record -> SurfaceInteraction: Triangle:: / BilinearPatch::InteractionFromIntersection --
  * (shapes.h:884-1010 and 1396-1489, run by the shapes' Intersect on every reported hit; with
  * the SurfaceInteraction constructor and SetShadingGeometry, interaction.h:32-33, 164-214).  A
@@ -343,8 +383,10 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value);
 /* diagnostics: wavefront scheduling statistics accumulated since the last reset —
  * out = {interior trips, interior lanes, primitive trips, primitive lanes, refill trips,
  * refill lanes, and over the interior trips the sums of lanes waiting on an interior node,
- * on a primitive, idle; one spare}.  All zero unless built with -DNNBVH_STATS. */
-int nnbvh_scene_sched_stats(nnbvh_scene *s, uint64_t out[10], int reset);
+ * on a primitive, idle; one spare; shader cycles spent in interior / primitive / refill trips; one
+ * spare; interior steps executed and the lanes that took part}.  All zero unless built with
+ * -DNNBVH_STATS. */
+int nnbvh_scene_sched_stats(nnbvh_scene *s, uint64_t out[16], int reset);
 
 #ifdef __cplusplus
 }

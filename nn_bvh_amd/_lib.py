@@ -49,7 +49,10 @@ EXPORTS = [
     "nnbvh_wavefront_intersect_shadow", "nnbvh_build_create_gpu", "nnbvh_build_gpu_timing",
     "nnbvh_shading_mesh_create", "nnbvh_shading_mesh_destroy", "nnbvh_triangle_interactions_device",
     "nnbvh_triangle_interactions", "nnbvh_scene_create_gpu_build",
-    "nnbvh_shading_mesh_set_instances",
+    "nnbvh_shading_mesh_set_instances", "nnbvh_wavefront_record_shadow_device",
+    "nnbvh_film_create", "nnbvh_film_destroy", "nnbvh_film_clear", "nnbvh_film_add_samples_device",
+    "nnbvh_film_pixels_device", "nnbvh_film_read", "nnbvh_film_pack_pixels_device",
+    "nnbvh_film_unpack_pixels_device",
 ]
 
 _lib = None
@@ -135,6 +138,24 @@ def lib():
     L.nnbvh_wavefront_intersect_closest.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp]
     L.nnbvh_wavefront_intersect_shadow.restype = i32
     L.nnbvh_wavefront_intersect_shadow.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
+    L.nnbvh_wavefront_record_shadow_device.restype = i32
+    L.nnbvh_wavefront_record_shadow_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    L.nnbvh_film_create.restype = vp
+    L.nnbvh_film_create.argtypes = [i32, i32, i32, i32, ctypes.c_float, i32]
+    L.nnbvh_film_destroy.restype = None
+    L.nnbvh_film_destroy.argtypes = [vp]
+    L.nnbvh_film_clear.restype = i32
+    L.nnbvh_film_clear.argtypes = [vp, vp]
+    L.nnbvh_film_add_samples_device.restype = i32
+    L.nnbvh_film_add_samples_device.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, vp, vp]
+    L.nnbvh_film_pixels_device.restype = i32
+    L.nnbvh_film_pixels_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    L.nnbvh_film_read.restype = i32
+    L.nnbvh_film_read.argtypes = [vp, vp]
+    L.nnbvh_film_pack_pixels_device.restype = i32
+    L.nnbvh_film_pack_pixels_device.argtypes = [vp, vp, i64, vp, vp]
+    L.nnbvh_film_unpack_pixels_device.restype = i32
+    L.nnbvh_film_unpack_pixels_device.argtypes = [vp, vp, i64, vp, vp]
     L.nnbvh_scene_sched_stats.restype = i32
     L.nnbvh_scene_sched_stats.argtypes = [vp, vp, i32]
     _lib = L

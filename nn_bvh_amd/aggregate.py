@@ -194,10 +194,12 @@ class BVHAggregate:
 
     def sched_stats(self, reset=True):
         """Diagnostics (NNBVH_STATS builds): trips and lanes per step kind."""
-        out = np.zeros(10, np.uint64)
+        out = np.zeros(16, np.uint64)
         check(_lib.lib().nnbvh_scene_sched_stats(self._h, ptr(out), int(reset)), "sched_stats")
         return dict(zip(("int_trips", "int_lanes", "prim_trips", "prim_lanes", "refill_trips",
-                         "refill_lanes", "i_nint", "i_nprim", "i_nidle"), (int(x) for x in out)))
+                         "refill_lanes", "i_nint", "i_nprim", "i_nidle", "spare0", "int_cycles",
+                         "prim_cycles", "refill_cycles", "spare1", "int_steps", "int_step_lanes"),
+                        (int(x) for x in out)))
 
     # -- reference interface ----------------------------------------------------------
     def Bounds(self):

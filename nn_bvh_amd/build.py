@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnnbvh_hip.so")
-SOURCES = ["bvh_trace.hip", "wavefront.hip", "bvh_build_gpu.hip", "bvh_bake.hip", "interaction.hip", "bvh_capi.cpp", "bvh_build.cpp"]
+SOURCES = ["bvh_trace.hip", "wavefront.hip", "bvh_build_gpu.hip", "bvh_bake.hip", "interaction.hip", "film.hip", "bvh_capi.cpp", "bvh_build.cpp"]
 HEADERS = ["bvh_trace.h", "wavefront.h", "bvh_build_gpu.h", "interaction.h", "nnbvh_internal.h", os.path.join("..", "..", "include", "nnbvh.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

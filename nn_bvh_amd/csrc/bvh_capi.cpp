@@ -584,17 +584,17 @@ int nnbvh_scene_info(const nnbvh_scene *s, int64_t out[6]) {
     return NNBVH_OK;
 }
 
-int nnbvh_scene_sched_stats(nnbvh_scene *s, uint64_t out[10], int reset) {
+int nnbvh_scene_sched_stats(nnbvh_scene *s, uint64_t out[16], int reset) {
     if (!s || !out) {
         set_error("scene_sched_stats: null argument");
         return NNBVH_ERR_ARG;
     }
-    std::memset(out, 0, 10 * sizeof(uint64_t));
+    std::memset(out, 0, 16 * sizeof(uint64_t));
     if (!s->d_stats) return NNBVH_OK;
     DeviceGuard guard(s->device);
     if (!guard.ok) return NNBVH_ERR_DEVICE;
     if (!hip_ok(hipDeviceSynchronize(), "scene_sched_stats") ||
-        !hip_ok(hipMemcpy(out, s->d_stats, 10 * sizeof(uint64_t), hipMemcpyDeviceToHost),
+        !hip_ok(hipMemcpy(out, s->d_stats, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost),
                 "scene_sched_stats"))
         return NNBVH_ERR_DEVICE;
     if (reset) (void)hipMemset(s->d_stats, 0, 16 * sizeof(unsigned long long));
@@ -886,6 +886,26 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
     if (rc != NNBVH_OK) return rc;
     if (!hip_ok(launch_wf_record_shadow(occ, cnt, d_Ld, d_r_u, d_r_l, d_pixel_index, d_L, (long)n_pixels,
                                         max_blocks, stream),
+                "shadow record kernel launch"))
+        return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
+}
+
+int nnbvh_wavefront_record_shadow_device(const uint8_t *d_occluded, int32_t max_rays, const int32_t *d_size,
+                                         const float *d_Ld, const float *d_r_u, const float *d_r_l,
+                                         const int32_t *d_pixel_index, float *d_L, int64_t n_pixels,
+                                         int device, void *stream_) {
+    if (max_rays < 0 || n_pixels < 0 ||
+        (max_rays > 0 && (!d_occluded || !d_Ld || !d_r_u || !d_r_l || !d_pixel_index || !d_L))) {
+        set_error("wavefront_record_shadow_device: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    if (max_rays == 0) return NNBVH_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    const WavefrontCount cnt{max_rays, d_size};
+    if (!hip_ok(launch_wf_record_shadow(d_occluded, cnt, d_Ld, d_r_u, d_r_l, d_pixel_index, d_L,
+                                        (long)n_pixels, 256 * 8, (hipStream_t)stream_),
                 "shadow record kernel launch"))
         return NNBVH_ERR_DEVICE;
     return NNBVH_OK;

@@ -408,7 +408,12 @@ void trace_kernel(TraceParams p) {
     }
 
 #ifdef NNBVH_STATS
-    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // trips/lanes per kind (I, P, R); [6..8] = sum nInt,nPrim,nIdle over I trips
+    // trips/lanes per kind (I, P, R); [6..8] = sum nInt,nPrim,nIdle over I trips; [10..12] = shader
+    // cycles (s_memtime) spent in I / P / R trips incl. their scheduling decision; [14], [15] =
+    // interior steps executed and the lanes that took part in them
+    unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stPrev = __builtin_amdgcn_s_memtime();
+    int stKind = 2;
 #endif
     RayState r;
     float tMax = 0.0f;
@@ -499,6 +504,13 @@ void trace_kernel(TraceParams p) {
     };
 
     for (;;) {
+#ifdef NNBVH_STATS
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            st[10 + stKind] += now - stPrev;
+            stPrev = now;
+        }
+#endif
         const bool isInt = cur >= 0;
         const bool isIdle = cur == kDone;
         const int nInt = __popcll(__ballot(isInt));
@@ -518,6 +530,7 @@ void trace_kernel(TraceParams p) {
         (&stTrips)[0] += 1;
         (&stTrips)[1] += (nIdle == 64 || (sR > sI && sR > sP)) ? nIdle
                          : ((sP > sI || nInt == 0) ? nPrim : nInt);
+        stKind = (&stTrips == &st[4]) ? 2 : ((&stTrips == &st[2]) ? 1 : 0);
         if (&stTrips == &st[0]) {
             st[6] += nInt;
             st[7] += nPrim;
@@ -672,6 +685,10 @@ void trace_kernel(TraceParams p) {
             // decision (lanes that leave the interior state sit the remaining ones out) -------
             for (int rep = 0; rep < p.intRepeat; ++rep) {
                 if (rep > 0 && __ballot(cur >= 0) == 0ull) break;
+#ifdef NNBVH_STATS
+                st[14] += 1;
+                st[15] += __popcll(__ballot(cur >= 0));
+#endif
                 if (cur < 0) continue;
                 const float4 *rec = p.wide + 4 * (long)cur;
                 const float4 q3 = rec[3];
@@ -709,7 +726,7 @@ void trace_kernel(TraceParams p) {
     }
 #ifdef NNBVH_STATS
     if (lane == 0 && p.stats)
-        for (int k = 0; k < 10; ++k) atomicAdd(&p.stats[k], st[k]);
+        for (int k = 0; k < 16; ++k) atomicAdd(&p.stats[k], st[k]);
 #endif
 }
 

@@ -1,0 +1,90 @@
+"""Host-side mirror of the film entry points (include/nnbvh.h, nnbvh_film_*): RGBFilm's pixel
+accumulators on the device (/root/reference/src/pbrt/film.h:239-255, 302-307) and the tile
+all-gather of a sharded render.  Buffers are torch CUDA tensors or raw device pointers; all work
+happens in libnnbvh_hip.so."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+def _dp(t):
+    """device pointer of a torch tensor / int / None"""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t if isinstance(t, int) else t.data_ptr())
+
+
+class Film:
+    def __init__(self, xres, yres, max_component_value=float("inf"), device=0, x0=0, y0=0):
+        self.bounds = (x0, y0, x0 + xres, y0 + yres)
+        self.device = device
+        self._h = _lib.lib().nnbvh_film_create(x0, y0, x0 + xres, y0 + yres,
+                                               ctypes.c_float(max_component_value), device)
+        if not self._h:
+            raise _lib.NNBVHError(f"nnbvh_film_create failed: {_lib.last_error()}")
+        self.n_pixels = xres * yres
+
+    def close(self):
+        if self._h:
+            _lib.lib().nnbvh_film_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self, stream=0):
+        check(_lib.lib().nnbvh_film_clear(self._h, ctypes.c_void_p(stream)), "nnbvh_film_clear")
+
+    def add_samples_device(self, px, py, rgb, weight, n_per_pass, n_passes=1, rgb_stride=3, d_size=None,
+                           stream=0):
+        """UpdateFilm + RGBFilm::AddSample for n_passes samples of n_per_pass distinct pixels."""
+        check(_lib.lib().nnbvh_film_add_samples_device(self._h, _dp(px), _dp(py), _dp(rgb), rgb_stride,
+                                                       _dp(weight), n_per_pass, n_passes, _dp(d_size),
+                                                       ctypes.c_void_p(stream)),
+              "nnbvh_film_add_samples_device")
+
+    def pixels_ptr(self):
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        check(_lib.lib().nnbvh_film_pixels_device(self._h, ctypes.byref(p), ctypes.byref(n)),
+              "nnbvh_film_pixels_device")
+        return p.value, n.value
+
+    def read(self):
+        """Synchronous copy: float64 [n_pixels, 4] = rgbSum[3], weightSum per pixel."""
+        out = np.zeros((self.n_pixels, 4), np.float64)
+        check(_lib.lib().nnbvh_film_read(self._h, _lib.ptr(out)), "nnbvh_film_read")
+        return out
+
+    def pack(self, d_index, n, d_out, stream=0):
+        check(_lib.lib().nnbvh_film_pack_pixels_device(self._h, _dp(d_index), n, _dp(d_out),
+                                                       ctypes.c_void_p(stream)), "nnbvh_film_pack_pixels_device")
+
+    def unpack(self, d_index, n, d_in, stream=0):
+        check(_lib.lib().nnbvh_film_unpack_pixels_device(self._h, _dp(d_index), n, _dp(d_in),
+                                                         ctypes.c_void_p(stream)), "nnbvh_film_unpack_pixels_device")
+
+    def all_gather_tiles(self, index_lists, rank, stream=0, group=None):
+        """The film all-gather of a tile-sharded render: index_lists[r] = int32 CUDA tensor of the
+        linear pixel indices rank r owns.  Packs this rank's pixels, ONE all_gather_into_tensor
+        (RCCL over xGMI under the nccl backend; ranks pad to the largest shard), unpacks the other
+        ranks' pixels into this film.  Returns the bytes this rank sent."""
+        import torch
+        import torch.distributed as dist
+        world = len(index_lists)
+        width = max(int(ix.numel()) for ix in index_lists)
+        dev = index_lists[rank].device
+        send = torch.zeros((width, 4), dtype=torch.float64, device=dev)
+        self.pack(index_lists[rank], int(index_lists[rank].numel()), send, stream)
+        out = torch.empty((world * width, 4), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(out, send, group=group)
+        out = out.view(world, width, 4)
+        for r in range(world):
+            if r != rank:
+                self.unpack(index_lists[r], int(index_lists[r].numel()), out[r], stream)
+        return width * 32

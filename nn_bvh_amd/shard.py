@@ -63,3 +63,24 @@ def assemble(parts, index_lists, n_total, dtype):
     for recs, idx in zip(parts, index_lists):
         full[idx] = np.frombuffer(bytes(recs), dtype) if not isinstance(recs, np.ndarray) else recs
     return full
+
+
+def all_gather_film(pixels, index_lists, rank, group=None):
+    """Film all-gather on a torch float64 [n_pixels, 4] tensor (RGBFilm::Pixel: rgbSum[3],
+    weightSum): rank r owns the pixels index_lists[r] (torch int64 tensors on the same device).
+    One all_gather_into_tensor of the padded per-rank pixel lists; the other ranks' pixels are
+    written into `pixels` in place.  The device film does the same with its pack / unpack kernels
+    (nn_bvh_amd.film.Film.all_gather_tiles); this form serves CPU tensors (gloo) and tests."""
+    import torch
+    import torch.distributed as dist
+    world = len(index_lists)
+    width = max(int(ix.numel()) for ix in index_lists)
+    send = torch.zeros((width, 4), dtype=torch.float64, device=pixels.device)
+    send[: index_lists[rank].numel()] = pixels[index_lists[rank]]
+    out = torch.empty((world * width, 4), dtype=torch.float64, device=pixels.device)
+    dist.all_gather_into_tensor(out, send, group=group)
+    out = out.view(world, width, 4)
+    for r in range(world):
+        if r != rank:
+            pixels[index_lists[r]] = out[r, : index_lists[r].numel()]
+    return pixels

@@ -1307,3 +1307,31 @@ void orc_transform_interaction_batch(const float *in72, int n, float *out40) {
         out40[40 * (size_t)i + 39] = 0;
     }
 }
+
+/* ---- film: wavefront/film.cpp:13-40 (UpdateFilm) + film.h:239-255 (RGBFilm::AddSample) --------- */
+void orc_film_add_samples(double *pixels, const int32_t bounds[4], float max_component,
+                          const int32_t *px, const int32_t *py, const float *rgb, int rgb_stride,
+                          const float *weight, int n_per_pass, int n_passes) {
+    const int x0 = bounds[0], y0 = bounds[1], x1 = bounds[2], y1 = bounds[3];
+    for (int pass = 0; pass < n_passes; ++pass) {
+        for (int i = 0; i < n_per_pass; ++i) {
+            const int x = px[i], y = py[i];
+            if (x < x0 || x >= x1 || y < y0 || y >= y1) continue; /* film.cpp:18-19 */
+            const long k = (long)pass * n_per_pass + i;
+            float c[3] = {rgb[k * rgb_stride], rgb[k * rgb_stride + 1], rgb[k * rgb_stride + 2]};
+            const float w = weight ? weight[k] : 1.0f;
+            float m = c[0]; /* film.h:245 std::max({r, g, b}) */
+            if (m < c[1]) m = c[1];
+            if (m < c[2]) m = c[2];
+            if (m > max_component) { /* film.h:246-247 rgb *= maxComponentValue / m */
+                const float s = max_component / m;
+                c[0] *= s;
+                c[1] *= s;
+                c[2] *= s;
+            }
+            double *pixel = pixels + 4 * ((long)(y - y0) * (x1 - x0) + (x - x0));
+            for (int ch = 0; ch < 3; ++ch) pixel[ch] += (double)(w * c[ch]); /* film.h:252-253 */
+            pixel[3] += (double)w;                                            /* film.h:254 */
+        }
+    }
+}

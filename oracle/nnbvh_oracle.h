@@ -115,6 +115,13 @@ void orc_wavefront_enqueue_closest(const orc_hit *hits, int n, const uint8_t *ha
 void orc_record_shadow(const uint8_t *occluded, int n, const float *Ld, const float *r_u,
                        const float *r_l, const int32_t *pixel_index, float *L);
 
+/* UpdateFilm + RGBFilm::AddSample (wavefront/film.cpp:13-40, film.h:239-255) without the spectral
+ * sensor conversion: sample (pass, i) of pixel slot i adds weight * clamp(rgb) to pixels[4 * pixel]
+ * (double rgbSum[3], weightSum; film.h:302-307), passes in order.  bounds = x0 y0 x1 y1. */
+void orc_film_add_samples(double *pixels, const int32_t bounds[4], float max_component,
+                          const int32_t *px, const int32_t *py, const float *rgb, int rgb_stride,
+                          const float *weight, int n_per_pass, int n_passes);
+
 /* Triangle::InteractionFromIntersection (shapes.h:884-1010): 44-float record, layout in the .c;
  * uv6 / n9 / s9 NULL = mesh without that attribute */
 int orc_triangle_interaction(const float p9[9], const float *uv6, const float *n9, const float *s9,

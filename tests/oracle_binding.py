@@ -204,3 +204,17 @@ def transform_interaction_batch(records72):
     out = np.zeros((len(rec), 40), np.float32)
     lib().orc_transform_interaction_batch(_p(rec), ctypes.c_int(len(rec)), _p(out))
     return out
+
+
+def film_add_samples(pixels, bounds, max_component, px, py, rgb, weight, n_passes):
+    """UpdateFilm + RGBFilm::AddSample on a float64 [n_pixels, 4] array, in place."""
+    px, py = np.ascontiguousarray(px, np.int32), np.ascontiguousarray(py, np.int32)
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    weight = None if weight is None else np.ascontiguousarray(weight, np.float32)
+    b = np.asarray(bounds, np.int32)
+    assert pixels.dtype == np.float64 and pixels.flags.c_contiguous
+    assert rgb.shape[0] == len(px) * n_passes
+    lib().orc_film_add_samples(_p(pixels), _p(b), ctypes.c_float(max_component), _p(px), _p(py), _p(rgb),
+                               ctypes.c_int(rgb.shape[1]), _p(weight), ctypes.c_int(len(px)),
+                               ctypes.c_int(n_passes))
+    return pixels

@@ -90,7 +90,14 @@ def main():
                           f"P {st['prim_trips'] * 64 / n[kind]:.1f} R {st['refill_trips'] * 64 / n[kind]:.2f}"
                           f" lanes/trip {util} during I trips: waiting-on-prim "
                           f"{st['i_nprim'] / max(1, st['int_trips']):.1f} idle "
-                          f"{st['i_nidle'] / max(1, st['int_trips']):.1f}")
+                          f"{st['i_nidle'] / max(1, st['int_trips']):.1f}; cycles/trip I "
+                          f"{st['int_cycles'] / max(1, st['int_trips']):.0f} P "
+                          f"{st['prim_cycles'] / max(1, st['prim_trips']):.0f} R "
+                          f"{st['refill_cycles'] / max(1, st['refill_trips']):.0f}; share of wave time I "
+                          f"{st['int_cycles'] / max(1, st['int_cycles'] + st['prim_cycles'] + st['refill_cycles']):.2f} P "
+                          f"{st['prim_cycles'] / max(1, st['int_cycles'] + st['prim_cycles'] + st['refill_cycles']):.2f}; "
+                          f"interior steps/trip {st['int_steps'] / max(1, st['int_trips']):.2f} lanes/step "
+                          f"{st['int_step_lanes'] / max(1, st['int_steps']):.1f}")
                 elif args.stats:
                     agg.sched_stats()
     print(f"# {source}; rays: {n}")
