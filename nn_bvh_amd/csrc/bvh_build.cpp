@@ -554,6 +554,11 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
                 nnbvh::set_error("nnbvh_build_create: instance / host primitives need prim_bounds");
                 return nullptr;
             }
+            for (int k = 0; k < 6; ++k)
+                if (!std::isfinite(prim_bounds[6 * (size_t)i + k])) {
+                    nnbvh::set_error("nnbvh_build_create: non-finite vertex or primitive bounds");
+                    return nullptr;
+                }
             bp[i].bounds.add(prim_bounds + 6 * (size_t)i);
             bp[i].bounds.add(prim_bounds + 6 * (size_t)i + 3);
             continue;
@@ -567,7 +572,14 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
                 nnbvh::set_error("nnbvh_build_create: vertex index out of range");
                 return nullptr;
             }
-            bp[i].bounds.add(verts + 3 * (size_t)p.v[k]);
+            // Inf / NaN coordinates are malformed input, not a tree: the reference's bucket index
+            // int(nBuckets * centroidBounds.Offset(c)) (aggregates.cpp:254-258) is undefined for them
+            const float *v = verts + 3 * (size_t)p.v[k];
+            if (!(std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]))) {
+                nnbvh::set_error("nnbvh_build_create: non-finite vertex or primitive bounds");
+                return nullptr;
+            }
+            bp[i].bounds.add(v);
         }
     }
     Builder b;

@@ -46,7 +46,7 @@ namespace {
 constexpr int kB = 256;
 constexpr int kTreeletBit = 18;  // bits >= 18 separate treelets (mask 0x3ffc0000, aggregates.cpp:423)
 
-enum : int { kErrVertex = 1, kErrNeedBounds = 2, kErrKind = 3, kErrLeafSize = 4 };
+enum : int { kErrVertex = 1, kErrNeedBounds = 2, kErrKind = 3, kErrLeafSize = 4, kErrNonFinite = 5 };
 enum : unsigned char { kRealInterior = 1, kRealLeaf = 2, kTreeletRoot = 4 };
 
 struct Box6 {
@@ -116,6 +116,19 @@ __global__ __launch_bounds__(kB) void k_prim_bounds(const nnbvh_prim *__restrict
                 continue;
             }
             box_add(b, verts + 3 * (long)vi);
+        }
+        // non-finite coordinates (Inf / NaN vertices or caller bounds) are malformed input: the
+        // bucket index int(nBuckets * offset) of aggregates.cpp:254-258 is undefined for them
+        for (int k = 0; k < nv; ++k) {
+            const int vi = p.v[k];
+            if (vi < 0 || vi >= nVerts) continue;
+            const float *v = verts + 3 * (long)vi;
+            if (!(__builtin_isfinite(v[0]) && __builtin_isfinite(v[1]) && __builtin_isfinite(v[2]))) *err = kErrNonFinite;
+        }
+        if ((p.kind == NNBVH_PRIM_INSTANCE || p.kind == NNBVH_PRIM_HOST) && callerBounds) {
+            const float *c = callerBounds + 6 * (long)i;
+            for (int k = 0; k < 6; ++k)
+                if (!__builtin_isfinite(c[k])) *err = kErrNonFinite;
         }
         pb[i] = b;
         for (int k = 0; k < 3; ++k) {
@@ -552,6 +565,7 @@ bool gpu_hlbvh(const nnbvh_prim *prims, int n, const float *verts, int n_verts,
     if (scal[6] != 0) {
         *error = scal[6] == kErrVertex       ? "nnbvh_build_create: vertex index out of range"
                  : scal[6] == kErrNeedBounds ? "nnbvh_build_create: instance / host primitives need prim_bounds"
+                 : scal[6] == kErrNonFinite  ? "nnbvh_build_create: non-finite vertex or primitive bounds"
                                              : "nnbvh_build_create: unknown primitive kind";
         return false;
     }
@@ -1407,6 +1421,7 @@ bool gpu_sah(const nnbvh_prim *prims, int n, const float *verts, int n_verts, co
     if (errNow != 0) {
         *error = errNow == kErrVertex       ? "nnbvh_build_create: vertex index out of range"
                  : errNow == kErrNeedBounds ? "nnbvh_build_create: instance / host primitives need prim_bounds"
+                 : errNow == kErrNonFinite  ? "nnbvh_build_create: non-finite vertex or primitive bounds"
                                             : "nnbvh_build_create: unknown primitive kind";
         return false;
     }

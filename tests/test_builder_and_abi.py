@@ -87,6 +87,29 @@ def test_builder_is_deterministic_and_rejects_bad_input(nnbvh_lib):
         build_tree(prims[:0], verts)
 
 
+@pytest.mark.parametrize("bad_value", [np.inf, -np.inf, np.nan])
+@pytest.mark.parametrize("method", ["sah", "hlbvh", "middle", "equal"])
+def test_builder_rejects_non_finite_vertices_and_bounds(nnbvh_lib, bad_value, method):
+    """A +-Inf / NaN coordinate makes the reference's bucket index int(nBuckets * Offset(c))
+    (aggregates.cpp:254-258) undefined (round 1's builder wrote out of bounds there): it is
+    malformed input and must be an error for every split method."""
+    verts, prims = ss.random_soup(64, 0, 9)
+    v = verts.copy()
+    v[prims["v"][17, 1], 2] = bad_value
+    with pytest.raises(NNBVHError, match="non-finite"):
+        build_tree(prims, v, 4, method)
+    # an unreferenced bad vertex is nobody's business
+    v2 = np.concatenate([verts, np.full((1, 3), bad_value, np.float32)])
+    assert build_tree(prims, v2, 4, method).nodes.tobytes() == build_tree(prims, verts, 4, method).nodes.tobytes()
+    # caller-supplied bounds of host / instance primitives
+    allp = np.concatenate([prims, np.zeros(1, prims.dtype)])
+    allp["kind"][-1], allp["id"][-1] = 3, len(prims)
+    pb = np.zeros((len(allp), 6), np.float32)
+    pb[-1] = [0, 0, 0, 1, 1, bad_value]
+    with pytest.raises(NNBVHError, match="non-finite"):
+        build_tree(allp, verts, 4, method, prim_bounds=pb)
+
+
 def test_library_exports_every_symbol_the_header_declares(nnbvh_lib):
     header = open(os.path.join(ROOT, "include", "nnbvh.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)

@@ -115,6 +115,31 @@ def test_bad_vertex_index_is_an_error_not_a_fault():
         build_tree_gpu(prims, verts)
 
 
+@pytest.mark.parametrize("method", ["sah", "hlbvh"])
+@pytest.mark.parametrize("bad_value", [np.inf, np.nan])
+def test_non_finite_vertex_is_an_error_on_the_device_too(method, bad_value):
+    verts, prims = ss.random_soup(3000, 200, 9)
+    v = verts.copy()
+    v[prims["v"][1234, 0], 1] = bad_value
+    with pytest.raises(NNBVHError, match="non-finite"):
+        build_tree_gpu(prims, v, split_method=method)
+    with pytest.raises(NNBVHError, match="non-finite"):
+        build_tree(prims, v, 4, method)
+    from nn_bvh_amd import BVHAggregate
+    with pytest.raises(NNBVHError, match="non-finite"):
+        BVHAggregate.build_on_device(prims, v, 4, method)
+
+
+def test_thousands_of_single_leaf_treelets():
+    """The shape of the HLBVH bring-up abort recorded in DESIGN.md (7 500 primitives, every
+    primitive its own Morton code, > 3 000 treelets of one leaf each): a sparse soup spread over the
+    whole Morton grid."""
+    verts, prims = ss.random_soup(7500, 0, 41, extent=400.0, size=0.01)
+    host = same_tree(prims, verts, what="sparse soup", method="hlbvh")
+    assert (host.nodes["nprims"] > 0).sum() > 3000
+    same_tree(prims, verts, what="sparse soup", method="sah")
+
+
 @pytest.mark.parametrize("name", ["killeroos", "bathroom", "crown"])
 def test_scene_blobs(name):
     if not os.path.exists(os.path.join(os.path.dirname(__file__), "..", "data", name + ".npz")):
@@ -183,6 +208,13 @@ def traces_identically(prims, verts, rays, method, prim_bounds=None, what=""):
     assert a.tobytes() == b.tobytes(), f"{what}: closest-hit records differ"
     for x, y in zip(host.IntersectP(rays, counts=True), dev.IntersectP(rays, counts=True)):
         assert np.array_equal(x, y), f"{what}: any-hit results differ"
+    # ... and the checker is the oracle, not the product: the device-built scene against the CPU
+    # restatement of BVHAggregate::Intersect / IntersectP walking the host builder's tree
+    import oracle_binding as ob
+    exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays)
+    assert b.tobytes() == exp.tobytes(), f"{what}: device-built scene differs from the oracle (closest)"
+    for x, y in zip(ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays), dev.IntersectP(rays, counts=True)):
+        assert np.array_equal(x, y), f"{what}: device-built scene differs from the oracle (any hit)"
     host.close()
     dev.close()
     return a

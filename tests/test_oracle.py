@@ -138,19 +138,28 @@ def test_reference_aggregates_recorded_in_survey(name, nodes, depth, v_closest, 
     """Outputs of the REFERENCE BVHAggregate recorded in SURVEY.md §6 / BASELINE.md §2 for the
     scenes' pixel-centre primary rays: node count, tree depth, mean nodes visited (V) and mean
     triangle tests (T), closest and any hit.  Our builder + oracle traversal must reproduce them
-    to the digits recorded.  Needs the git-ignored scene blob (build container / GPU box)."""
+    on ALL pixel centres to the digits recorded (half a unit of the last recorded digit).  This is
+    the strongest reference anchor the traversal loop has (BVHAggregate itself cannot be built
+    here: DESIGN.md §2); per-ray parity with the reference stays unpinned.  The survey's bounce-ray
+    rows are not used: its bounce generator is not specified to the bit, and ours (same recipe,
+    own random stream) gives crown V = 93.0 / T = 7.73 against the recorded 89.4 / 6.95.
+    Needs the git-ignored scene blob (build container / GPU box)."""
     if not os.path.exists(scene.blob_path(name)):
         pytest.skip(f"data/{name}.npz not present")
     from nn_bvh_amd import make_prims
     verts, tris = scene.load_blob(name)
     tree = build_tree(make_prims(tris), verts)
     assert len(tree.nodes) == nodes and tree.depth == depth
-    # every 2nd pixel centre (all of them for the small killeroos film)
-    rays = scene.camera_rays(name, jitter=False, subsample=1 if name == "killeroos" else 2)
+    rays = scene.camera_rays(name, jitter=False)
     nthreads = min(8, os.cpu_count() or 1)
     h = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, nthreads)
-    assert abs(h["nodes_visited"].mean() - v_closest) < 0.012 * v_closest
-    assert abs(h["prim_tests"].mean() - t_closest) < 0.012 * t_closest
+
+    def agrees(measured, recorded):
+        digits = len(repr(recorded).split(".")[1])
+        return abs(measured - recorded) <= 0.5 * 10.0 ** -digits
+
+    assert agrees(h["nodes_visited"].mean(), v_closest), h["nodes_visited"].mean()
+    assert agrees(h["prim_tests"].mean(), t_closest), h["prim_tests"].mean()
     _, vis, tst = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, nthreads)
-    assert abs(vis.mean() - v_any) < 0.012 * v_any
-    assert abs(tst.mean() - t_any) < 0.012 * t_any
+    assert agrees(vis.mean(), v_any), vis.mean()
+    assert agrees(tst.mean(), t_any), tst.mean()

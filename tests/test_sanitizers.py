@@ -51,8 +51,22 @@ DRIVER = textwrap.dedent(r'''
                     nnbvh_build_destroy(b);
                 }
         }
+        // non-finite coordinates are rejected, never indexed with (round 1: SIGSEGV in the bucket loop)
+        for (float bad : {1.0f / 0.0f, -1.0f / 0.0f, 0.0f / 0.0f}) {
+            std::vector<float> verts;
+            std::vector<nnbvh_prim> prims;
+            for (int i = 0; i < 64; ++i) {
+                int base = (int)verts.size() / 3;
+                for (int k = 0; k < 9; ++k) verts.push_back(5 * U(rng));
+                prims.push_back(nnbvh_prim{0, i, {base, base + 1, base + 2, 0}});
+            }
+            verts[3 * 40 + 1] = bad;
+            for (int method : {NNBVH_SPLIT_SAH, NNBVH_SPLIT_HLBVH, NNBVH_SPLIT_MIDDLE, NNBVH_SPLIT_EQUAL_COUNTS})
+                if (nnbvh_build_create(prims.data(), 64, verts.data(), (int)verts.size() / 3, 4, method)) return 6;
+        }
         // the host half of the GPU HLBVH build: upper SAH tree + DFS layout over treelet roots
-        for (int nt : {1, 2, 37, 4096}) {
+        // (3392 = the shape of the round-1 bring-up abort: thousands of treelets of ONE leaf each)
+        for (int nt : {1, 2, 37, 4096, 3392}) {
             std::vector<float> tb(6 * (size_t)nt);
             std::vector<int> ts(nt);
             for (int t = 0; t < nt; ++t) {
@@ -60,7 +74,7 @@ DRIVER = textwrap.dedent(r'''
                     tb[6 * t + a] = 50 * U(rng);
                     tb[6 * t + 3 + a] = tb[6 * t + a] + 1 + U(rng) * 0.5f;
                 }
-                ts[t] = 1 + 2 * (int)(rng() % 9);
+                ts[t] = nt == 3392 ? 1 : 1 + 2 * (int)(rng() % 9);
             }
             nnbvh::UpperLayout up;
             std::string err;
