@@ -372,6 +372,56 @@ int nnbvh_triangle_interactions_device(const nnbvh_shading_mesh *m, const void *
                                        int32_t max_items, const int32_t *d_size, void *d_out,
                                        void *stream);
 
+/* ---- KdTreeAggregate (cpu/aggregates.h:75-105; aggregates.cpp:746-1161) --------------------------
+ * The reference's other accelerator ("kdtree" in CreateAccelerator, aggregates.cpp:1163-1178) and the
+ * native structure of the learned trees of machine_learning/nss_*.py.
+ *   nnbvh_kd_node             <- KdTreeNode (aggregates.cpp:753-775): 8 B; interior = {Float split,
+ *                                flags = axis | aboveChild << 2} with the below child at index + 1; leaf =
+ *                                {onePrimitiveIndex | primitiveIndicesOffset, flags = 3 | nPrimitives << 2}
+ *   nnbvh_kd_build_create     <- KdTreeAggregate ctor + buildTree (aggregates.cpp:798-971), host-side
+ *   nnbvh_kd_scene_create     <- takes what KdTreeAggregate owns after construction: nodes,
+ *                                primitiveIndices, the primitives in their ORIGINAL order, bounds
+ *   nnbvh_kd_intersect_*      <- KdTreeAggregate::Intersect / IntersectP (aggregates.cpp:973-1150);
+ *                                nodes_visited = kdNodesVisited (aggregates.cpp:796), prim_tests =
+ *                                nTriTests; a primitive that overlaps several leaves is tested in each
+ *                                (the reference has no mailboxing). */
+typedef struct nnbvh_kd_node {
+    uint32_t split_or_index; /* bit pattern of the float split position, or the leaf's int32 */
+    uint32_t flags;
+} nnbvh_kd_node;
+typedef struct nnbvh_kd_build nnbvh_kd_build;
+typedef struct nnbvh_kd_scene nnbvh_kd_scene;
+/* defaults of KdTreeAggregate::Create (aggregates.cpp:1152-1161): isect_cost 5, traversal_cost 1,
+ * empty_bonus 0.5, max_prims 1, max_depth -1 (= round(8 + 1.3 log2 n)).  prim_bounds as for
+ * nnbvh_build_create_with_bounds (read for NNBVH_PRIM_HOST entries).  Triangles, patches and
+ * host-only primitives; instances are not accepted. */
+nnbvh_kd_build *nnbvh_kd_build_create(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
+                                      const float *prim_bounds, int isect_cost, int traversal_cost,
+                                      float empty_bonus, int max_prims, int max_depth);
+const nnbvh_kd_node *nnbvh_kd_build_nodes(const nnbvh_kd_build *b, int *n_nodes);
+const int32_t *nnbvh_kd_build_prim_indices(const nnbvh_kd_build *b, int *n_indices);
+int nnbvh_kd_build_bounds(const nnbvh_kd_build *b, float out_min_max[6]);
+int nnbvh_kd_build_depth(const nnbvh_kd_build *b); /* edges root -> deepest node */
+void nnbvh_kd_build_destroy(nnbvh_kd_build *b);
+
+/* The tree is validated (child links, leaf ranges, primitive indices, depth <= 64 = the reference's
+ * toVisit[64], aggregates.cpp:982) before anything is uploaded.  prims: n_prims primitives indexed
+ * by the leaves; hit.prim reports nnbvh_prim.id. */
+nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, const int32_t *prim_indices,
+                                      int n_indices, const nnbvh_prim *prims, int n_prims,
+                                      const float *verts, int n_verts, const float bounds_min_max[6],
+                                      int device);
+void nnbvh_kd_scene_destroy(nnbvh_kd_scene *s);
+/* host buffers (synchronous) */
+int nnbvh_kd_intersect_closest(nnbvh_kd_scene *s, const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits);
+int nnbvh_kd_intersect_any(nnbvh_kd_scene *s, const nnbvh_ray *rays, int64_t n, uint8_t *occluded,
+                           int32_t *nodes_visited, int32_t *prim_tests);
+/* device buffers, asynchronous on `stream` */
+int nnbvh_kd_intersect_closest_device(nnbvh_kd_scene *s, const void *d_rays, int64_t n, void *d_hits,
+                                      void *stream);
+int nnbvh_kd_intersect_any_device(nnbvh_kd_scene *s, const void *d_rays, int64_t n, void *d_occluded,
+                                  void *d_nodes_visited, void *d_prim_tests, void *stream);
+
 /* tuning knobs (speed only, never results): "stack_window" (LDS entries per lane: 4, 8, 16),
  * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "prim_weight" / "refill_weight" (1..64:
  * how much a lane waiting on a primitive test / an idle lane counts against a lane waiting on

@@ -20,6 +20,7 @@ BATCH_DTYPE = np.dtype([("kind", "<i4"), ("pad", "<i4"), ("d_rays", "<u8"), ("n"
                         ("d_out", "<u8"), ("d_nodes_visited", "<u8"), ("d_prim_tests", "<u8")])
 HIT_DTYPE = np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"),
                       ("nodes_visited", "<i4"), ("prim_tests", "<i4"), ("instance", "<i4")])
+KD_NODE_DTYPE = np.dtype([("split_or_index", "<u4"), ("flags", "<u4")])
 RAY_SOA_DTYPE = np.dtype([(k, "<u8") for k in ("ox", "oy", "oz", "dx", "dy", "dz", "time", "tmax",
                                                 "has_medium")])
 WORK_QUEUE_DTYPE = np.dtype([("items", "<u8"), ("size", "<u8"), ("capacity", "<i4"), ("pad", "<i4")])
@@ -52,7 +53,10 @@ EXPORTS = [
     "nnbvh_shading_mesh_set_instances", "nnbvh_wavefront_record_shadow_device",
     "nnbvh_film_create", "nnbvh_film_destroy", "nnbvh_film_clear", "nnbvh_film_add_samples_device",
     "nnbvh_film_pixels_device", "nnbvh_film_read", "nnbvh_film_pack_pixels_device",
-    "nnbvh_film_unpack_pixels_device",
+    "nnbvh_film_unpack_pixels_device", "nnbvh_kd_build_create", "nnbvh_kd_build_nodes",
+    "nnbvh_kd_build_prim_indices", "nnbvh_kd_build_bounds", "nnbvh_kd_build_depth", "nnbvh_kd_build_destroy",
+    "nnbvh_kd_scene_create", "nnbvh_kd_scene_destroy", "nnbvh_kd_intersect_closest", "nnbvh_kd_intersect_any",
+    "nnbvh_kd_intersect_closest_device", "nnbvh_kd_intersect_any_device",
 ]
 
 _lib = None
@@ -156,6 +160,30 @@ def lib():
     L.nnbvh_film_pack_pixels_device.argtypes = [vp, vp, i64, vp, vp]
     L.nnbvh_film_unpack_pixels_device.restype = i32
     L.nnbvh_film_unpack_pixels_device.argtypes = [vp, vp, i64, vp, vp]
+    L.nnbvh_kd_build_create.restype = vp
+    L.nnbvh_kd_build_create.argtypes = [vp, i32, vp, i32, vp, i32, i32, ctypes.c_float, i32, i32]
+    L.nnbvh_kd_build_nodes.restype = vp
+    L.nnbvh_kd_build_nodes.argtypes = [vp, ctypes.POINTER(i32)]
+    L.nnbvh_kd_build_prim_indices.restype = vp
+    L.nnbvh_kd_build_prim_indices.argtypes = [vp, ctypes.POINTER(i32)]
+    L.nnbvh_kd_build_bounds.restype = i32
+    L.nnbvh_kd_build_bounds.argtypes = [vp, vp]
+    L.nnbvh_kd_build_depth.restype = i32
+    L.nnbvh_kd_build_depth.argtypes = [vp]
+    L.nnbvh_kd_build_destroy.restype = None
+    L.nnbvh_kd_build_destroy.argtypes = [vp]
+    L.nnbvh_kd_scene_create.restype = vp
+    L.nnbvh_kd_scene_create.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32]
+    L.nnbvh_kd_scene_destroy.restype = None
+    L.nnbvh_kd_scene_destroy.argtypes = [vp]
+    L.nnbvh_kd_intersect_closest.restype = i32
+    L.nnbvh_kd_intersect_closest.argtypes = [vp, vp, i64, vp]
+    L.nnbvh_kd_intersect_any.restype = i32
+    L.nnbvh_kd_intersect_any.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.nnbvh_kd_intersect_closest_device.restype = i32
+    L.nnbvh_kd_intersect_closest_device.argtypes = [vp, vp, i64, vp, vp]
+    L.nnbvh_kd_intersect_any_device.restype = i32
+    L.nnbvh_kd_intersect_any_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.nnbvh_scene_sched_stats.restype = i32
     L.nnbvh_scene_sched_stats.argtypes = [vp, vp, i32]
     _lib = L

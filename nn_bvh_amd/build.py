@@ -10,8 +10,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnnbvh_hip.so")
-SOURCES = ["bvh_trace.hip", "wavefront.hip", "bvh_build_gpu.hip", "bvh_bake.hip", "interaction.hip", "film.hip", "bvh_capi.cpp", "bvh_build.cpp"]
-HEADERS = ["bvh_trace.h", "wavefront.h", "bvh_build_gpu.h", "interaction.h", "nnbvh_internal.h", os.path.join("..", "..", "include", "nnbvh.h")]
+SOURCES = ["bvh_trace.hip", "wavefront.hip", "bvh_build_gpu.hip", "bvh_bake.hip", "interaction.hip", "film.hip", "kd_trace.hip", "bvh_capi.cpp", "bvh_build.cpp", "kd_build.cpp"]
+HEADERS = ["bvh_trace.h", "trace_math.h", "wavefront.h", "bvh_build_gpu.h", "interaction.h", "nnbvh_internal.h", os.path.join("..", "..", "include", "nnbvh.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 
@@ -29,6 +29,18 @@ def build_stats(verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = os.path.join(HERE, "libnnbvh_hip_stats.so")
     cmd = [hipcc] + FLAGS + ["-DNNBVH_STATS", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out
+
+
+def build_variant(name, defines, verbose=False):
+    """Experimental build nn_bvh_amd/libnnbvh_hip_<name>.so with extra -D flags (select it with
+    NNBVH_LIB=libnnbvh_hip_<name>.so); never the product."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = os.path.join(HERE, f"libnnbvh_hip_{name}.so")
+    cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -27,8 +27,10 @@ __global__ __launch_bounds__(kBk) void k_bake_slot_counts(const nnbvh_prim *__re
     if (i >= n) return;
     const int kind = prims[i].kind;
     int c = 3;  // triangle, host-only primitive
-    if (kind == NNBVH_PRIM_BILINEAR_PATCH) c = 4;
-    else if (kind == NNBVH_PRIM_HOST) atomicOr(flags, 1);
+    if (kind == NNBVH_PRIM_BILINEAR_PATCH) {
+        c = 4;
+        atomicOr(flags, 4);
+    } else if (kind == NNBVH_PRIM_HOST) atomicOr(flags, 1);
     else if (kind != NNBVH_PRIM_TRIANGLE) atomicOr(flags, 2);  // instances are not baked here
     slots[i] = c;
 }
@@ -209,6 +211,7 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
     std::memcpy(out->bounds, root.pmin, 12);
     std::memcpy(out->bounds + 3, root.pmax, 12);
     out->has_host_prims = flags & 1;
+    out->has_patches = (flags & 4) ? 1 : 0;
     return true;
 }
 

@@ -75,6 +75,7 @@ struct nnbvh_scene {
     unsigned long long *d_stats = nullptr;  // diagnostics (NNBVH_STATS builds)
     int instanced = 0;      // two-level scene: use the INST kernels
     int has_host_prims = 0;
+    int has_patches = 1;    // 0: no bilinear patches, the lean kernels (no ray direction parked in LDS) run
     int int_repeat = 3;
     int max_grid_threads = 0;
     double build_ms[1] = {0};  // device build time of nnbvh_scene_create_gpu_build
@@ -213,6 +214,7 @@ static nnbvh_scene *scene_from_baked(const BakedScene &b, int depth, int device)
     s->root_ref = b.root_ref;
     s->instanced = 0;
     s->has_host_prims = b.has_host_prims;
+    s->has_patches = b.has_patches;
     s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
     s->d_wide = (float4 *)b.d_wide;
     s->d_prims = (float4 *)b.d_prims;
@@ -413,6 +415,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     s->root_ref = ref_of(0);
     s->instanced = n_instances > 0 ? 1 : 0;
     s->has_host_prims = has_host ? 1 : 0;
+    s->has_patches = 1;  // two-level scenes always run the general kernels
     s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
     const size_t wide_bytes = wide.size() * sizeof(WideNode);
     const size_t prim_bytes = std::max<size_t>((size_t)n_slots, 1) * 16;
@@ -561,7 +564,7 @@ static int grid_blocks(nnbvh_scene *s, int mode) {
     if (per_cu <= 0) {
         TraceParams dummy{};
         int occ = 0;
-        if (launch_trace(mode, dummy, s->window, s->instanced, 0, nullptr, &occ) != hipSuccess ||
+        if (launch_trace(mode, dummy, s->window, s->instanced, s->has_patches, 0, nullptr, &occ) != hipSuccess ||
             occ <= 0)
             occ = std::max(1, std::min(8, 160 / (s->window * 2)));
         per_cu = occ;
@@ -696,7 +699,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     int blocks = grid_blocks(s, mode);
     const int64_t need = (n + kBlockThreads - 1) / kBlockThreads;
     if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
-    if (!hip_ok(launch_trace(mode, p, s->window, s->instanced, blocks, stream, nullptr),
+    if (!hip_ok(launch_trace(mode, p, s->window, s->instanced, s->has_patches, blocks, stream, nullptr),
                 "trace kernel launch"))
         return NNBVH_ERR_DEVICE;
     return NNBVH_OK;

@@ -1335,3 +1335,220 @@ void orc_film_add_samples(double *pixels, const int32_t bounds[4], float max_com
         }
     }
 }
+
+/* ---- KdTreeAggregate, cpu/aggregates.cpp:746-1150 ---------------------------------------------- */
+/* Bounds3::IntersectP(Point3f o, Vector3f d, Float tMax, Float *hitt0, Float *hitt1),
+ * util/vecmath.h:1547-1571 */
+int orc_bounds_t0t1(const float bounds[6], const float o[3], const float d[3], float tmax, float t0t1[2]) {
+    float t0 = 0, t1 = tmax;
+    for (int i = 0; i < 3; ++i) {
+        float invRayDir = 1 / d[i];
+        float tNear = (bounds[i] - o[i]) * invRayDir;
+        float tFar = (bounds[3 + i] - o[i]) * invRayDir;
+        if (tNear > tFar) {
+            float s = tNear;
+            tNear = tFar;
+            tFar = s;
+        }
+        tFar *= 1 + 2 * orc_gamma(3);
+        t0 = tNear > t0 ? tNear : t0;
+        t1 = tFar < t1 ? tFar : t1;
+        if (t0 > t1) return 0;
+    }
+    t0t1[0] = t0;
+    t0t1[1] = t1;
+    return 1;
+}
+
+void orc_bounds_t0t1_batch(const float *bounds6, const float *o3, const float *d3, const float *tmax, int n,
+                           uint8_t *hit, float *t0t1) {
+    for (int i = 0; i < n; ++i) {
+        t0t1[2 * i] = t0t1[2 * i + 1] = 0.0f;
+        hit[i] = (uint8_t)orc_bounds_t0t1(bounds6 + 6 * i, o3 + 3 * i, d3 + 3 * i, tmax[i], t0t1 + 2 * i);
+    }
+}
+
+typedef struct {
+    int node;
+    float tMin, tMax;
+} kd_to_visit; /* KdNodeToVisit, aggregates.cpp:747-750 */
+
+static inline float kd_split(const orc_kd_node *n) {
+    float f;
+    memcpy(&f, &n->split_or_index, 4);
+    return f;
+}
+
+/* closest = 1: KdTreeAggregate::Intersect (:973-1067); 0: IntersectP (:1069-1150) */
+static void kd_one(const orc_kd_node *nodes, const int32_t *prim_indices, const orc_prim *prims,
+                   const float *verts, const float bounds[6], const orc_ray *ray, int closest, orc_hit *hit,
+                   uint8_t *occ, int32_t *visited_out, int32_t *tests_out) {
+    float rayTMax = ray->tmax;
+    const float *o = ray->o, *d = ray->d;
+    int nodesVisited = 0, tests = 0, host = 0, found = 0;
+    if (closest) {
+        hit->prim = -1;
+        hit->t = rayTMax;
+        hit->b0 = hit->b1 = hit->b2 = 0.0f;
+        hit->instance = 0;
+    }
+    float tt[2];
+    if (orc_bounds_t0t1(bounds, o, d, rayTMax, tt)) {
+        float tMin = tt[0], tMax = tt[1];
+        const float invDir[3] = {1 / d[0], 1 / d[1], 1 / d[2]};
+        kd_to_visit toVisit[64];
+        int toVisitIndex = 0;
+        int node = 0;
+        while (node >= 0) {
+            if (closest && rayTMax < tMin) break; /* :989-991 */
+            ++nodesVisited;
+            const orc_kd_node *nd = &nodes[node];
+            if ((nd->flags & 3) != 3) { /* interior, :993-1023 / :1110-1144 */
+                const int axis = (int)(nd->flags & 3);
+                const float split = kd_split(nd);
+                const float tSplit = (split - o[axis]) * invDir[axis];
+                const int belowFirst = (o[axis] < split) || (o[axis] == split && d[axis] <= 0);
+                int firstChild, secondChild;
+                if (belowFirst) {
+                    firstChild = node + 1;
+                    secondChild = (int)(nd->flags >> 2);
+                } else {
+                    firstChild = (int)(nd->flags >> 2);
+                    secondChild = node + 1;
+                }
+                if (tSplit > tMax || tSplit <= 0)
+                    node = firstChild;
+                else if (tSplit < tMin)
+                    node = secondChild;
+                else {
+                    toVisit[toVisitIndex].node = secondChild;
+                    toVisit[toVisitIndex].tMin = tSplit;
+                    toVisit[toVisitIndex].tMax = tMax;
+                    ++toVisitIndex;
+                    node = firstChild;
+                    tMax = tSplit;
+                }
+            } else { /* leaf, :1025-1061 / :1084-1107 */
+                const int nPrimitives = (int)(nd->flags >> 2);
+                for (int i = 0; i < nPrimitives && !found; ++i) {
+                    const int index = nPrimitives == 1 ? (int32_t)nd->split_or_index
+                                                       : prim_indices[(int32_t)nd->split_or_index + i];
+                    const orc_prim *p = &prims[index];
+                    float r[4];
+                    if (p->kind == 3) { /* host-only primitive: the record is void */
+                        host = 1;
+                        continue;
+                    }
+                    ++tests;
+                    if (prim_test(p, verts, o, d, rayTMax, r)) {
+                        if (closest) {
+                            hit->prim = p->id;
+                            hit->b0 = r[0];
+                            hit->b1 = r[1];
+                            hit->b2 = r[2];
+                            hit->t = r[3];
+                            rayTMax = r[3];
+                        } else {
+                            found = 1; /* :1091-1094, :1101-1104: return true */
+                        }
+                    }
+                }
+                if (found) break;
+                if (toVisitIndex > 0) {
+                    --toVisitIndex;
+                    node = toVisit[toVisitIndex].node;
+                    tMin = toVisit[toVisitIndex].tMin;
+                    tMax = toVisit[toVisitIndex].tMax;
+                } else
+                    break;
+            }
+        }
+    }
+    if (closest) {
+        hit->nodes_visited = nodesVisited;
+        hit->prim_tests = tests;
+        if (host) hit->instance = -1;
+    } else {
+        *occ = found ? 1 : (host ? 2 : 0);
+        if (visited_out) *visited_out = nodesVisited;
+        if (tests_out) *tests_out = tests;
+    }
+}
+
+typedef struct {
+    const orc_kd_node *nodes;
+    const int32_t *prim_indices;
+    const orc_prim *prims;
+    const float *verts;
+    const float *bounds;
+    const orc_ray *rays;
+    orc_hit *hits;
+    uint8_t *occ;
+    int32_t *visited, *tests;
+    int64_t begin, end;
+} kd_job;
+
+static void *kd_worker(void *arg) {
+    kd_job *j = (kd_job *)arg;
+    for (int64_t i = j->begin; i < j->end; ++i) {
+        if (j->hits)
+            kd_one(j->nodes, j->prim_indices, j->prims, j->verts, j->bounds, &j->rays[i], 1, &j->hits[i], NULL,
+                   NULL, NULL);
+        else
+            kd_one(j->nodes, j->prim_indices, j->prims, j->verts, j->bounds, &j->rays[i], 0, NULL, &j->occ[i],
+                   j->visited ? &j->visited[i] : NULL, j->tests ? &j->tests[i] : NULL);
+    }
+    return NULL;
+}
+
+static void kd_run(kd_job base, int64_t n, int nthreads) {
+    if (nthreads <= 1 || n < 2 * (int64_t)nthreads) {
+        base.begin = 0;
+        base.end = n;
+        kd_worker(&base);
+        return;
+    }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    kd_job *jobs = (kd_job *)malloc(sizeof(kd_job) * (size_t)nthreads);
+    for (int k = 0; k < nthreads; ++k) {
+        jobs[k] = base;
+        jobs[k].begin = n * k / nthreads;
+        jobs[k].end = n * (k + 1) / nthreads;
+        pthread_create(&th[k], NULL, kd_worker, &jobs[k]);
+    }
+    for (int k = 0; k < nthreads; ++k) pthread_join(th[k], NULL);
+    free(jobs);
+    free(th);
+}
+
+void orc_kd_intersect_closest(const orc_kd_node *nodes, const int32_t *prim_indices, const orc_prim *prims,
+                              const float *verts, const float bounds[6], const orc_ray *rays, int64_t n,
+                              orc_hit *hits, int nthreads) {
+    kd_job j;
+    memset(&j, 0, sizeof j);
+    j.nodes = nodes;
+    j.prim_indices = prim_indices;
+    j.prims = prims;
+    j.verts = verts;
+    j.bounds = bounds;
+    j.rays = rays;
+    j.hits = hits;
+    kd_run(j, n, nthreads);
+}
+
+void orc_kd_intersect_any(const orc_kd_node *nodes, const int32_t *prim_indices, const orc_prim *prims,
+                          const float *verts, const float bounds[6], const orc_ray *rays, int64_t n,
+                          uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests, int nthreads) {
+    kd_job j;
+    memset(&j, 0, sizeof j);
+    j.nodes = nodes;
+    j.prim_indices = prim_indices;
+    j.prims = prims;
+    j.verts = verts;
+    j.bounds = bounds;
+    j.rays = rays;
+    j.occ = occluded;
+    j.visited = nodes_visited;
+    j.tests = prim_tests;
+    kd_run(j, n, nthreads);
+}

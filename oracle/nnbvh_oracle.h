@@ -115,6 +115,26 @@ void orc_wavefront_enqueue_closest(const orc_hit *hits, int n, const uint8_t *ha
 void orc_record_shadow(const uint8_t *occluded, int n, const float *Ld, const float *r_u,
                        const float *r_l, const int32_t *pixel_index, float *L);
 
+/* == KdTreeNode, cpu/aggregates.cpp:753-775 (8 B): interior {float split; flags = axis | above << 2},
+ * leaf {int onePrimitiveIndex | primitiveIndicesOffset; flags = 3 | nPrimitives << 2} */
+typedef struct {
+    uint32_t split_or_index;
+    uint32_t flags;
+} orc_kd_node;
+/* Bounds3::IntersectP(o, d, tMax, *hitt0, *hitt1), util/vecmath.h:1547-1571: the entry / exit
+ * distances KdTreeAggregate starts from.  Returns 1 = hit and writes t0t1[2]. */
+int orc_bounds_t0t1(const float bounds[6], const float o[3], const float d[3], float tmax, float t0t1[2]);
+void orc_bounds_t0t1_batch(const float *bounds6, const float *o3, const float *d3, const float *tmax, int n,
+                           uint8_t *hit, float *t0t1);
+/* KdTreeAggregate::Intersect / IntersectP (aggregates.cpp:973-1150).  prims are indexed by the leaves
+ * (original order); hits carry nodes_visited = kdNodesVisited and prim_tests = nTriTests. */
+void orc_kd_intersect_closest(const orc_kd_node *nodes, const int32_t *prim_indices, const orc_prim *prims,
+                              const float *verts, const float bounds[6], const orc_ray *rays, int64_t n,
+                              orc_hit *hits, int nthreads);
+void orc_kd_intersect_any(const orc_kd_node *nodes, const int32_t *prim_indices, const orc_prim *prims,
+                          const float *verts, const float bounds[6], const orc_ray *rays, int64_t n,
+                          uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests, int nthreads);
+
 /* UpdateFilm + RGBFilm::AddSample (wavefront/film.cpp:13-40, film.h:239-255) without the spectral
  * sensor conversion: sample (pass, i) of pixel slot i adds weight * clamp(rgb) to pixels[4 * pixel]
  * (double rgbSum[3], weightSum; film.h:302-307), passes in order.  bounds = x0 y0 x1 y1. */
