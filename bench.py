@@ -80,10 +80,11 @@ def parse_args(argv=None):
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel traced per step")
     ap.add_argument("--sample-sets", type=int, default=4,
                     help="distinct sets of --spp samples kept resident and traced round-robin")
-    ap.add_argument("--tree", default="sah", choices=["sah", "hlbvh", "middle", "equal", "nn", "sah_gpu", "hlbvh_gpu"],
+    ap.add_argument("--tree", default="sah", choices=["sah", "hlbvh", "middle", "equal", "nn", "sah_gpu", "hlbvh_gpu", "kd"],
                     help="tree builder: pbrt split methods (host), nn = greedy-SAH top levels of "
                          "machine_learning/nn_BVH.py finished by SAH and baked (BASELINE config 5), "
-                         "*_gpu = the same sah / hlbvh tree built and baked on the device")
+                         "*_gpu = the same sah / hlbvh tree built and baked on the device, kd = the "
+                         "reference's KdTreeAggregate (aggregates.cpp:746-1161) on its own traversal kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wavefront", action="store_true",
                     help="also time the step through the wavefront-queue entry points")
@@ -214,7 +215,15 @@ def main():
     t0 = time.time()
     verts, tris, source = scene.load_scene(args.scene)
     prims = make_prims(tris)
-    if args.tree == "nn":
+    kd = None
+    if args.tree == "kd":
+        if args.overlapped or args.wavefront:
+            sys.exit("bench.py: --tree kd supports the plain step only")
+        from nn_bvh_amd.aggregate import BuiltTree
+        from nn_bvh_amd.kdtree import KdTreeAggregate, build_kd_tree
+        kd = build_kd_tree(prims, verts)
+        tree = BuiltTree(kd.nodes, kd.prim_indices, kd.depth)
+    elif args.tree == "nn":
         from nn_bvh_amd import nn_tree
         from nn_bvh_amd.aggregate import BuiltTree
         (nn_nodes, nn_ordered), _ = nn_tree.greedy_sah_tree(verts, tris, levels=4)
@@ -224,7 +233,10 @@ def main():
         tree = build_tree(prims, verts, 4, args.tree[:-4])
     else:
         tree = build_tree(prims, verts, 4, args.tree)
-    if args.tree in ("sah_gpu", "hlbvh_gpu"):
+    if kd is not None:
+        agg = KdTreeAggregate.from_tree(kd.nodes, kd.prim_indices, prims, verts, kd.bounds, device=local_rank)
+        agg.info = {"depth": kd.depth, "grid_blocks": -1, "stack_window": 8}
+    elif args.tree in ("sah_gpu", "hlbvh_gpu"):
         t_dev = time.time()
         agg = BVHAggregate.build_on_device(prims, verts, 4, args.tree[:-4], device=local_rank)
         if rank == 0:
@@ -411,10 +423,13 @@ def main():
     primary, bounce, shadow = s0["primary"], s0["bounce"], s0["shadow"]
     bhits = s0["d_bhits"].cpu().numpy().view(HIT_DTYPE)
 
-    # algorithmic bytes: 32 in + 32*V + 48*T + 32 out per closest-hit ray
+    # algorithmic bytes: 32 in + 32*V + 48*T + 32 out per closest-hit ray (a
+    # KdTreeNode is 8 B, and a leaf primitive costs its 4-B index besides the 48 B of the triangle)
+    node_bytes, prim_bytes = (8.0, 52.0) if kd is not None else (32.0, 48.0)
+
     def alg_bytes(h):
-        return 64.0 * len(h) + 32.0 * h["nodes_visited"].sum(dtype=np.int64) + \
-            48.0 * h["prim_tests"].sum(dtype=np.int64)
+        return 64.0 * len(h) + node_bytes * h["nodes_visited"].sum(dtype=np.int64) + \
+            prim_bytes * h["prim_tests"].sum(dtype=np.int64)
     bytes_closest = alg_bytes(hits) + alg_bytes(bhits)          # both launches of the kernel
     ms_closest = ms_primary + ms_bounce
     achieved = bytes_closest / (ms_closest * 1e-3) / 1e9         # GB/s over the kernel's launches
@@ -492,7 +507,7 @@ def main():
     # (profiles/; collected and corrected as MI355X_MICROARCH.md §HBM prescribes).  Only quoted when
     # the profile was taken at the same --spp on crown at N=1.
     prof = profile_counters()
-    if prof is not None and not (prof.get("spp") in (None, args.spp) and args.scene == "crown" and world == 1):
+    if prof is not None and not (prof.get("spp") in (None, args.spp) and args.scene == "crown" and world == 1 and kd is None):
         prof = None
     traffic = prof["hbm_bytes_per_launch"] if prof else None
 
@@ -551,7 +566,7 @@ def main():
                 # limiter the counters show and `valu_issue` / `hbm_physical` quantify it.
                 "bound": "hbm",
                 "label": "alg_hbm",
-                "kernel": "trace_kernel<closest>",
+                "kernel": "kd_trace_kernel<closest>" if kd is not None else "trace_kernel<closest>",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -615,6 +630,11 @@ def main():
         batches = (primary[sel], bounce[sel], shadow[sel])
 
         def cpu_pass():
+            if kd is not None:
+                a = ob.kd_closest(kd.nodes, kd.prim_indices, prims, verts, kd.bounds, batches[0], nthreads=cores)
+                b = ob.kd_closest(kd.nodes, kd.prim_indices, prims, verts, kd.bounds, batches[1], nthreads=cores)
+                c, _, _ = ob.kd_any_hit(kd.nodes, kd.prim_indices, prims, verts, kd.bounds, batches[2], nthreads=cores)
+                return a, b, c
             a = ob.closest(tree.nodes, tree.ordered_prims, verts, batches[0], nthreads=cores)
             b = ob.closest(tree.nodes, tree.ordered_prims, verts, batches[1], nthreads=cores)
             c, _, _ = ob.any_hit(tree.nodes, tree.ordered_prims, verts, batches[2], nthreads=cores)

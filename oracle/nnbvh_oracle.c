@@ -1552,3 +1552,150 @@ void orc_kd_intersect_any(const orc_kd_node *nodes, const int32_t *prim_indices,
     j.tests = prim_tests;
     kd_run(j, n, nthreads);
 }
+
+/* ---- util/hash.h ------------------------------------------------------------------------------ */
+static uint64_t orc_murmur64a(const unsigned char *key, size_t len, uint64_t seed) { /* hash.h:19-64 */
+    const uint64_t m = 0xc6a4a7935bd1e995ull;
+    const int r = 47;
+    uint64_t h = seed ^ (len * m);
+    const unsigned char *end = key + 8 * (len / 8);
+    while (key != end) {
+        uint64_t k;
+        memcpy(&k, key, sizeof(uint64_t));
+        key += 8;
+        k *= m;
+        k ^= k >> r;
+        k *= m;
+        h ^= k;
+        h *= m;
+    }
+    switch (len & 7) {
+    case 7: h ^= (uint64_t)key[6] << 48; /* fall through */
+    case 6: h ^= (uint64_t)key[5] << 40; /* fall through */
+    case 5: h ^= (uint64_t)key[4] << 32; /* fall through */
+    case 4: h ^= (uint64_t)key[3] << 24; /* fall through */
+    case 3: h ^= (uint64_t)key[2] << 16; /* fall through */
+    case 2: h ^= (uint64_t)key[1] << 8;  /* fall through */
+    case 1: h ^= (uint64_t)key[0]; h *= m;
+    };
+    h ^= h >> r;
+    h *= m;
+    h ^= h >> r;
+    return h;
+}
+
+uint64_t orc_hash_6f(const float a[3], const float b[3]) { /* Hash(args...), hash.h:111-118 */
+    uint64_t buf[3];
+    memcpy((char *)buf, a, 12);
+    memcpy((char *)buf + 12, b, 12);
+    return orc_murmur64a((const unsigned char *)buf, 24, 0);
+}
+
+float orc_hash_float_6f(const float a[3], const float b[3]) { /* hash.h:120-123 */
+    return (float)(uint32_t)orc_hash_6f(a, b) * 0x1p-32f;
+}
+
+static uint64_t orc_mix_bits(uint64_t v) { /* hash.h:70-77 */
+    v ^= (v >> 31);
+    v *= 0x7fb5d329728ea185ull;
+    v ^= (v >> 27);
+    v *= 0x81dadef4bc2dd44dull;
+    v ^= (v >> 33);
+    return v;
+}
+
+/* ---- util/rng.h: PCG32 -------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t state, inc;
+} orc_rng;
+static uint32_t orc_rng_u32(orc_rng *g) { /* rng.h:92-99 */
+    uint64_t oldstate = g->state;
+    g->state = oldstate * 0x5851f42d4c957f2dull + g->inc;
+    uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+    uint32_t rot = (uint32_t)(oldstate >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+static void orc_rng_set_sequence(orc_rng *g, uint64_t sequenceIndex) { /* rng.h:49-51, 130-136 */
+    const uint64_t seed = orc_mix_bits(sequenceIndex);
+    g->state = 0u;
+    g->inc = (sequenceIndex << 1u) | 1u;
+    orc_rng_u32(g);
+    g->state += seed;
+    orc_rng_u32(g);
+}
+static float orc_rng_float(orc_rng *g) { /* rng.h:138-141 */
+    const float v = (float)orc_rng_u32(g) * 0x1p-32f;
+    return v < 0x1.fffffep-1f ? v : 0x1.fffffep-1f;
+}
+
+int orc_wrs_unit_weights(uint64_t seed, int n_adds, float *sample_probability, float *weight_sum) {
+    orc_rng g; /* WeightedReservoirSampler(uint64_t rngSeed) : rng(rngSeed), sampling.h:529 */
+    orc_rng_set_sequence(&g, seed);
+    float weightSum = 0, reservoirWeight = 0;
+    int reservoir = -1;
+    for (int k = 0; k < n_adds; ++k) { /* Add(sample, weight), sampling.h:535-546 */
+        const float weight = 1.f;
+        weightSum += weight;
+        const float p = weight / weightSum;
+        if (orc_rng_float(&g) < p) {
+            reservoir = k;
+            reservoirWeight = weight;
+        }
+    }
+    if (sample_probability) *sample_probability = weightSum > 0 ? reservoirWeight / weightSum : 0.f;
+    if (weight_sum) *weight_sum = weightSum;
+    return weightSum > 0 ? reservoir : -1;
+}
+
+/* ---- ray.h:75-101 ------------------------------------------------------------------------------- */
+void orc_offset_ray_origin(const float lo[3], const float hi[3], const float n[3], const float w[3],
+                           float po[3]) {
+    /* pi.Error() = Width() / 2 (vecmath.h Point3fi::Error, math.h Interval::Width = high - low) */
+    const float ex = (hi[0] - lo[0]) / 2, ey = (hi[1] - lo[1]) / 2, ez = (hi[2] - lo[2]) / 2;
+    /* Dot(Normal3, Vector3) = FMA(n.x, v.x, SumOfProducts(n.y, v.y, n.z, v.z)), vecmath.h:1056-1068 */
+    const float an[3] = {fabsf(n[0]), fabsf(n[1]), fabsf(n[2])}, err[3] = {ex, ey, ez};
+    const float d = orc_dot_n(an, err);
+    float offset[3] = {d * n[0], d * n[1], d * n[2]};
+    if (orc_dot_n(n, w) < 0) {
+        offset[0] = -offset[0];
+        offset[1] = -offset[1];
+        offset[2] = -offset[2];
+    }
+    for (int i = 0; i < 3; ++i) {
+        po[i] = (lo[i] + hi[i]) / 2 + offset[i]; /* Point3f(pi): Interval::Midpoint */
+        if (offset[i] > 0)
+            po[i] = next_up(po[i]);
+        else if (offset[i] < 0)
+            po[i] = next_down(po[i]);
+    }
+}
+
+void orc_spawn_ray_to(const float lo[3], const float hi[3], const float n[3], const float p_to[3],
+                      float out_o[3], float out_d[3]) {
+    for (int i = 0; i < 3; ++i) out_d[i] = p_to[i] - (lo[i] + hi[i]) / 2; /* ray.h:99 */
+    orc_offset_ray_origin(lo, hi, n, out_d, out_o);
+}
+
+void orc_hash_batch(const float *in6, int n, uint32_t *lo, uint32_t *hi, float *hash_float) {
+    for (int i = 0; i < n; ++i) {
+        const uint64_t h = orc_hash_6f(in6 + 6 * i, in6 + 6 * i + 3);
+        lo[i] = (uint32_t)h;
+        hi[i] = (uint32_t)(h >> 32);
+        hash_float[i] = orc_hash_float_6f(in6 + 6 * i, in6 + 6 * i + 3);
+    }
+}
+
+void orc_offset_batch(const float *in12, int n, float *out9) {
+    for (int i = 0; i < n; ++i) {
+        const float *r = in12 + 12 * i;
+        orc_offset_ray_origin(r, r + 3, r + 6, r + 9, out9 + 9 * i);
+        orc_spawn_ray_to(r, r + 3, r + 6, r + 9, out9 + 9 * i + 3, out9 + 9 * i + 6);
+    }
+}
+
+void orc_wrs_batch(const float *in7, int n, int32_t *selected, float *out2) {
+    for (int i = 0; i < n; ++i) {
+        const float *r = in7 + 7 * i;
+        selected[i] = orc_wrs_unit_weights(orc_hash_6f(r, r + 3), (int)r[6], &out2[2 * i], &out2[2 * i + 1]);
+    }
+}

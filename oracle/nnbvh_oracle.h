@@ -135,6 +135,23 @@ void orc_kd_intersect_any(const orc_kd_node *nodes, const int32_t *prim_indices,
                           const float *verts, const float bounds[6], const orc_ray *rays, int64_t n,
                           uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests, int nthreads);
 
+/* util/hash.h:19-128: MurmurHash64A over the bytes of (a[3], b[3]) = Hash(Point3f, Vector3f) =
+ * Hash(Point3f, Point3f); HashFloat = uint32(hash) * 2^-32 */
+uint64_t orc_hash_6f(const float a[3], const float b[3]);
+float orc_hash_float_6f(const float a[3], const float b[3]);
+/* OffsetRayOrigin / SpawnRayTo (ray.h:75-101) on a Point3fi given as lo[3], hi[3] */
+void orc_offset_ray_origin(const float pi_lo[3], const float pi_hi[3], const float n[3], const float w[3],
+                           float out[3]);
+void orc_spawn_ray_to(const float pi_lo[3], const float pi_hi[3], const float n[3], const float p_to[3],
+                      float out_o[3], float out_d[3]);
+/* WeightedReservoirSampler<int> seeded with `seed` (util/sampling.h:524-596 on the PCG32 RNG of
+ * util/rng.h): n_adds candidates 0..n-1 of weight 1; returns the selected index (-1 = none) */
+int orc_wrs_unit_weights(uint64_t seed, int n_adds, float *sample_probability, float *weight_sum);
+/* batch drivers for the cross-checks against oracle/_ref/ref_leaf */
+void orc_hash_batch(const float *in6, int n, uint32_t *lo, uint32_t *hi, float *hash_float);
+void orc_offset_batch(const float *in12, int n, float *out9);
+void orc_wrs_batch(const float *in7, int n, int32_t *selected, float *out2);
+
 /* UpdateFilm + RGBFilm::AddSample (wavefront/film.cpp:13-40, film.h:239-255) without the spectral
  * sensor conversion: sample (pass, i) of pixel slot i adds weight * clamp(rgb) to pixels[4 * pixel]
  * (double rgbSum[3], weightSum; film.h:302-307), passes in order.  bounds = x0 y0 x1 y1. */

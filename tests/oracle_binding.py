@@ -218,3 +218,60 @@ def film_add_samples(pixels, bounds, max_component, px, py, rgb, weight, n_passe
                                ctypes.c_int(rgb.shape[1]), _p(weight), ctypes.c_int(len(px)),
                                ctypes.c_int(n_passes))
     return pixels
+
+
+def kd_closest(nodes, prim_indices, prims, verts, bounds, rays, nthreads=1):
+    from nn_bvh_amd._lib import HIT_DTYPE
+    nodes, prims = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+    idx = np.ascontiguousarray(prim_indices, np.int32)
+    verts, bounds = np.ascontiguousarray(verts, np.float32), np.ascontiguousarray(bounds, np.float32)
+    rays = np.ascontiguousarray(rays)
+    hits = np.zeros(len(rays), HIT_DTYPE)
+    lib().orc_kd_intersect_closest(_p(nodes), _p(idx), _p(prims), _p(verts), _p(bounds), _p(rays),
+                                   ctypes.c_int64(len(rays)), _p(hits), ctypes.c_int(nthreads))
+    return hits
+
+
+def kd_any_hit(nodes, prim_indices, prims, verts, bounds, rays, nthreads=1):
+    nodes, prims = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+    idx = np.ascontiguousarray(prim_indices, np.int32)
+    verts, bounds = np.ascontiguousarray(verts, np.float32), np.ascontiguousarray(bounds, np.float32)
+    rays = np.ascontiguousarray(rays)
+    occ = np.zeros(len(rays), np.uint8)
+    vis = np.zeros(len(rays), np.int32)
+    tst = np.zeros(len(rays), np.int32)
+    lib().orc_kd_intersect_any(_p(nodes), _p(idx), _p(prims), _p(verts), _p(bounds), _p(rays),
+                               ctypes.c_int64(len(rays)), _p(occ), _p(vis), _p(tst), ctypes.c_int(nthreads))
+    return occ, vis, tst
+
+
+def bounds_t0t1(bounds6, o3, d3, tmax):
+    n = len(tmax)
+    hit = np.zeros(n, np.uint8)
+    out = np.zeros((n, 2), np.float32)
+    b, o, d, t = (np.ascontiguousarray(a, np.float32) for a in (bounds6, o3, d3, tmax))  # keep alive
+    lib().orc_bounds_t0t1_batch(_p(b), _p(o), _p(d), _p(t), ctypes.c_int(n), _p(hit), _p(out))
+    return hit, out
+
+
+def hash_batch(in6):
+    in6 = np.ascontiguousarray(in6, np.float32)
+    n = len(in6)
+    lo, hi, hf = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.float32)
+    lib().orc_hash_batch(_p(in6), ctypes.c_int(n), _p(lo), _p(hi), _p(hf))
+    return lo, hi, hf
+
+
+def offset_batch(in12):
+    in12 = np.ascontiguousarray(in12, np.float32)
+    out = np.zeros((len(in12), 9), np.float32)
+    lib().orc_offset_batch(_p(in12), ctypes.c_int(len(in12)), _p(out))
+    return out
+
+
+def wrs_batch(in7):
+    in7 = np.ascontiguousarray(in7, np.float32)
+    sel = np.zeros(len(in7), np.int32)
+    out = np.zeros((len(in7), 2), np.float32)
+    lib().orc_wrs_batch(_p(in7), ctypes.c_int(len(in7)), _p(sel), _p(out))
+    return sel, out
