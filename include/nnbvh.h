@@ -218,10 +218,8 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
  * (intersect.h:32-47) on the device.  Output queues hold INDICES into the input queue: the
  * caller's material / light / escape stages gather their payload (beta, lambda, pixelIndex ...)
  * from the input work items by index, and the geometric part of the hit from d_hits[index].
- * Not covered (they need the media / material systems, out of this path's scope):
- * IntersectShadowTr and IntersectOneRandom (aggregate.cpp:70-116) — the reference only selects
- * them for scenes with participating media or subsurface materials (wavefront/integrator.cpp:
- * 91-110, 576-579). */
+ * IntersectShadowTr and IntersectOneRandom (aggregate.cpp:70-116) follow below in their media-free
+ * form; the media themselves (SampleT_maj along ray.medium) are outside this path's scope. */
 typedef struct nnbvh_ray_soa {   /* SOA<Ray> slices (workitems.soa:40-50, 82-88), device pointers */
     const float *ox, *oy, *oz;
     const float *dx, *dy, *dz;
@@ -266,6 +264,37 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
                                      const int32_t *d_size, const float *d_Ld, const float *d_r_u,
                                      const float *d_r_l, const int32_t *d_pixel_index, float *d_L,
                                      int64_t n_pixels, uint8_t *d_occluded, void *stream);
+
+/* WavefrontAggregate::IntersectShadowTr (wavefront/aggregate.cpp:70-88 -> TraceTransmittance,
+ * wavefront/intersect.h:164-274) for scenes WITHOUT participating media: a shadow ray passes
+ * through interface surfaces (NNBVH_CLASS_INTERFACE: no material) — closest hit, SpawnRayTo the light
+ * point from the hit (ray.h:75-101), again — and is blocked by the first surface that has a material;
+ * T_ray, r_u, r_l stay 1, so an arriving ray adds Ld * (1 / (r_u + r_l).Average()) to its pixel sample
+ * (intersect.h:258-273).  Needs the scene's shading mesh for the hit points (pi, n).  Runs as passes
+ * over the still-active rays; between passes the host reads one 4-byte count (not hipGraph-
+ * capturable).  d_state: optional uint8[max_rays]: 0 = arrived, 1 = blocked, 2 = a host-only
+ * primitive lies on the way (nothing added: the caller's to finish).  Media themselves (ray.medium,
+ * SampleT_maj) are outside this path's scope. */
+typedef struct nnbvh_shading_mesh nnbvh_shading_mesh;
+int nnbvh_wavefront_intersect_shadow_tr(nnbvh_scene *s, const nnbvh_shading_mesh *m, int32_t max_rays,
+                                        const nnbvh_ray_soa *shadow_queue, const int32_t *d_size,
+                                        const uint8_t *d_prim_class, int64_t n_prim_class, const float *d_Ld,
+                                        const float *d_r_u, const float *d_r_l, const int32_t *d_pixel_index,
+                                        float *d_L, int64_t n_pixels, uint8_t *d_state, void *stream);
+/* WavefrontAggregate::IntersectOneRandom (wavefront/aggregate.cpp:90-116; GPU form gpu/optix.cu:480-573):
+ * for every SubsurfaceScatterWorkItem {p0, p1, material} walk the segment p0 -> p1 surface by surface
+ * (SpawnRayTo(p1), Intersect(r, 1)) and keep ONE hit whose material equals the item's, chosen by
+ * WeightedReservoirSampler (util/sampling.h:524-596, unit weights, PCG32 seeded with Hash(p0, p1)).
+ * d_p0 / d_p1: 3 floats per item; d_material: the item's material id; d_prim_material: material id
+ * per primitive id (NULL = all 0).  Out per item: the selected hit record (prim = -1: none; instance =
+ * -1: a host-only primitive lies on the segment, the item is the caller's) and the ray of its segment
+ * (what nnbvh_triangle_interactions_device needs to produce the SubsurfaceInteraction), the
+ * reservoir's SampleProbability (0 without a sample) and, optionally, its weight sum. */
+int nnbvh_wavefront_intersect_one_random(nnbvh_scene *s, const nnbvh_shading_mesh *m, int32_t max_items,
+                                         const float *d_p0, const float *d_p1, const int32_t *d_material,
+                                         const int32_t *d_size, const int32_t *d_prim_material,
+                                         int64_t n_prim_material, void *d_sel_hits, void *d_sel_rays,
+                                         float *d_reservoir_pdf, float *d_weight_sum, void *stream);
 
 /* RecordShadowRayResult (wavefront/intersect.h:32-47) for a shadow batch that was traced with
  * nnbvh_intersect_any_device: the bookkeeping half of nnbvh_wavefront_intersect_shadow on its own. */
@@ -318,7 +347,6 @@ int nnbvh_film_unpack_pixels_device(nnbvh_film *f, const int32_t *d_index, int64
 #define NNBVH_TRI_HAS_UV 2      /* the triangle's mesh has uv / n / s (meshes of one scene differ) */
 #define NNBVH_TRI_HAS_N 4
 #define NNBVH_TRI_HAS_S 8
-typedef struct nnbvh_shading_mesh nnbvh_shading_mesh;
 /* tri_vertices: 3 vertex indices per primitive, primitive k being the one whose nnbvh_prim.id is k
  * (v[0] < 0: not a triangle).  patch_vertices (nullable): 4 per primitive, p00 p10 p01 p11
  * (v[0] < 0: not a bilinear patch; BilinearPatchMesh, util/mesh.h:50-72).  normals / tangents: 3

@@ -57,6 +57,7 @@ EXPORTS = [
     "nnbvh_kd_build_prim_indices", "nnbvh_kd_build_bounds", "nnbvh_kd_build_depth", "nnbvh_kd_build_destroy",
     "nnbvh_kd_scene_create", "nnbvh_kd_scene_destroy", "nnbvh_kd_intersect_closest", "nnbvh_kd_intersect_any",
     "nnbvh_kd_intersect_closest_device", "nnbvh_kd_intersect_any_device",
+    "nnbvh_wavefront_intersect_shadow_tr", "nnbvh_wavefront_intersect_one_random",
 ]
 
 _lib = None
@@ -184,6 +185,10 @@ def lib():
     L.nnbvh_kd_intersect_closest_device.argtypes = [vp, vp, i64, vp, vp]
     L.nnbvh_kd_intersect_any_device.restype = i32
     L.nnbvh_kd_intersect_any_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.nnbvh_wavefront_intersect_shadow_tr.restype = i32
+    L.nnbvh_wavefront_intersect_shadow_tr.argtypes = [vp, vp, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp]
+    L.nnbvh_wavefront_intersect_one_random.restype = i32
+    L.nnbvh_wavefront_intersect_one_random.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]
     L.nnbvh_scene_sched_stats.restype = i32
     L.nnbvh_scene_sched_stats.argtypes = [vp, vp, i32]
     _lib = L

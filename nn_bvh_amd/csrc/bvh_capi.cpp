@@ -19,6 +19,7 @@
 #include "bvh_build_gpu.h"
 #include "interaction.h"
 #include "wavefront.h"
+#include "wavefront2.h"
 
 namespace nnbvh {
 
@@ -81,6 +82,10 @@ struct nnbvh_scene {
     double build_ms[1] = {0};  // device build time of nnbvh_scene_create_gpu_build
     std::mutex mu;
     std::map<hipStream_t, Workspace> workspaces;
+    // grow-only scratch of the multi-pass entry points (IntersectShadowTr / IntersectOneRandom)
+    static constexpr int kScratch = 12;
+    void *scratch[kScratch] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[kScratch] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // fork/join machinery of nnbvh_trace_batches_device
     static constexpr int kSideStreams = 4;
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
@@ -541,6 +546,8 @@ void nnbvh_scene_destroy(nnbvh_scene *s) {
         if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]);
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    for (void *p : s->scratch)
+        if (p) (void)hipFree(p);
     (void)hipFree(s->d_wide);
     (void)hipFree(s->d_prims);
     if (s->d_stats) (void)hipFree(s->d_stats);
@@ -1058,6 +1065,159 @@ int nnbvh_triangle_interactions(const nnbvh_shading_mesh *m, const nnbvh_ray *ra
     for (void *p : {d_rays, d_hits, d_out})
         if (p) (void)hipFree(p);
     return rc;
+}
+
+// ---- IntersectShadowTr / IntersectOneRandom (wavefront/aggregate.cpp:70-116), media-free -------------
+// Host-driven loops of device passes; the only host round trip per pass is the 4-byte count of
+// items that go on (interface surfaces are rare: the usual shadow batch ends after its first pass).
+static bool scratch(nnbvh_scene *s, int slot, size_t bytes, void **out) {
+    if (!grow(&s->scratch[slot], &s->scratch_bytes[slot], std::max<size_t>(bytes, 16), "hipMalloc(wavefront scratch)"))
+        return false;
+    *out = s->scratch[slot];
+    return true;
+}
+
+static bool read_count(const int32_t *d_counter, hipStream_t stream, int *out) {
+    int32_t v = 0;
+    if (!hip_ok(hipMemcpyAsync(&v, d_counter, 4, hipMemcpyDeviceToHost, stream), "read pass count") ||
+        !hip_ok(hipStreamSynchronize(stream), "wavefront pass"))
+        return false;
+    *out = v;
+    return true;
+}
+
+int nnbvh_wavefront_intersect_shadow_tr(nnbvh_scene *s, const nnbvh_shading_mesh *m, int32_t max_rays,
+                                        const nnbvh_ray_soa *shadow_queue, const int32_t *d_size,
+                                        const uint8_t *d_prim_class, int64_t n_prim_class, const float *d_Ld,
+                                        const float *d_r_u, const float *d_r_l, const int32_t *d_pixel_index,
+                                        float *d_L, int64_t n_pixels, uint8_t *d_state, void *stream_) {
+    if (!s || !m || max_rays < 0 || n_pixels < 0 || n_prim_class < 0 ||
+        (max_rays > 0 && (!soa_ok(shadow_queue) || !d_Ld || !d_r_u || !d_r_l || !d_pixel_index || !d_L))) {
+        set_error("wavefront_intersect_shadow_tr: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    if (m->device != s->device) {
+        set_error("wavefront_intersect_shadow_tr: scene and shading mesh live on different devices");
+        return NNBVH_ERR_ARG;
+    }
+    if (max_rays == 0) return NNBVH_OK;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(s->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    Workspace *w = workspace_for(s, stream);
+    if (!w) return NNBVH_ERR_DEVICE;
+    const size_t n = (size_t)max_rays;
+    void *raysA, *raysB, *hitsA, *hitsB, *origA, *origB, *pLight, *state, *counters, *intr;
+    if (!scratch(s, 0, n * 32, &raysA) || !scratch(s, 1, n * 32, &raysB) || !scratch(s, 2, n * 32, &hitsA) ||
+        !scratch(s, 3, n * 32, &hitsB) || !scratch(s, 4, n * 4, &origA) || !scratch(s, 5, n * 4, &origB) ||
+        !scratch(s, 6, n * 16, &pLight) || !scratch(s, 7, n, &state) || !scratch(s, 8, 64, &counters))
+        return NNBVH_ERR_DEVICE;
+    int32_t *nCur = (int32_t *)counters, *nNext = nCur + 1;
+    const WavefrontCount cnt{max_rays, d_size};
+    const int max_blocks = s->n_cus * 8;
+    if (!hip_ok(launch_str_init(*shadow_queue, cnt, raysA, (int32_t *)origA, (float4 *)pLight, (uint8_t *)state,
+                                max_blocks, stream), "shadow-tr init launch"))
+        return NNBVH_ERR_DEVICE;
+    // the first pass covers the whole queue: its size is max_rays clamped by *d_size
+    if (d_size) {
+        if (!hip_ok(hipMemcpyAsync(nCur, d_size, 4, hipMemcpyDeviceToDevice, stream), "copy queue size"))
+            return NNBVH_ERR_DEVICE;
+    } else if (!hip_ok(hipMemcpyAsync(nCur, &max_rays, 4, hipMemcpyHostToDevice, stream), "copy queue size")) {
+        return NNBVH_ERR_DEVICE;
+    }
+    int active = max_rays;
+    for (int pass = 0; active > 0; ++pass) {
+        if (pass > 4096) {
+            set_error("wavefront_intersect_shadow_tr: more than 4096 interface surfaces on one shadow ray");
+            return NNBVH_ERR_ARG;
+        }
+        int rc = launch(s, 0, raysA, active, hitsA, nullptr, nullptr, nullptr, stream, w, nCur);
+        if (rc != NNBVH_OK) return rc;
+        if (!hip_ok(hipMemsetAsync(nNext, 0, 4, stream), "reset pass count") ||
+            !hip_ok(launch_str_classify(raysA, hitsA, (const int32_t *)origA, nCur, d_prim_class, (long)n_prim_class,
+                                        (uint8_t *)state, raysB, hitsB, (int32_t *)origB, nNext, active, max_blocks,
+                                        stream), "shadow-tr classify launch"))
+            return NNBVH_ERR_DEVICE;
+        int n_iface = 0;
+        if (!read_count(nNext, stream, &n_iface)) return NNBVH_ERR_DEVICE;
+        if (n_iface <= 0) break;
+        if (!scratch(s, 9, (size_t)n_iface * sizeof(nnbvh_interaction), &intr)) return NNBVH_ERR_DEVICE;
+        if (!hip_ok(launch_triangle_interactions(m->d, raysB, nullptr, hitsB, n_iface, nNext, intr, m->n_cus * 8, stream),
+                    "interaction kernel launch") ||
+            !hip_ok(hipMemsetAsync(nCur, 0, 4, stream), "reset pass count") ||
+            !hip_ok(launch_str_spawn(raysB, intr, (const int32_t *)origB, nNext, (const float4 *)pLight, (uint8_t *)state,
+                                     raysA, (int32_t *)origA, nCur, n_iface, max_blocks, stream), "shadow-tr spawn launch"))
+            return NNBVH_ERR_DEVICE;
+        if (!read_count(nCur, stream, &active)) return NNBVH_ERR_DEVICE;
+    }
+    if (!hip_ok(launch_str_record((const uint8_t *)state, cnt, d_Ld, d_r_u, d_r_l, d_pixel_index, d_L, (long)n_pixels,
+                                  d_state, max_blocks, stream), "shadow-tr record launch"))
+        return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
+}
+
+int nnbvh_wavefront_intersect_one_random(nnbvh_scene *s, const nnbvh_shading_mesh *m, int32_t max_items,
+                                         const float *d_p0, const float *d_p1, const int32_t *d_material,
+                                         const int32_t *d_size, const int32_t *d_prim_material,
+                                         int64_t n_prim_material, void *d_sel_hits, void *d_sel_rays,
+                                         float *d_reservoir_pdf, float *d_weight_sum, void *stream_) {
+    if (!s || !m || max_items < 0 || n_prim_material < 0 ||
+        (max_items > 0 && (!d_p0 || !d_p1 || !d_material || !d_sel_hits || !d_sel_rays || !d_reservoir_pdf))) {
+        set_error("wavefront_intersect_one_random: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    if (m->device != s->device) {
+        set_error("wavefront_intersect_one_random: scene and shading mesh live on different devices");
+        return NNBVH_ERR_ARG;
+    }
+    if (max_items == 0) return NNBVH_OK;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(s->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    Workspace *w = workspace_for(s, stream);
+    if (!w) return NNBVH_ERR_DEVICE;
+    const size_t n = (size_t)max_items;
+    void *raysA, *raysB, *hits, *origA, *origB, *pi, *rng, *weights, *counters, *intr;
+    if (!scratch(s, 0, n * 32, &raysA) || !scratch(s, 1, n * 32, &raysB) || !scratch(s, 2, n * 32, &hits) ||
+        !scratch(s, 4, n * 4, &origA) || !scratch(s, 5, n * 4, &origB) || !scratch(s, 6, n * 36, &pi) ||
+        !scratch(s, 10, n * 16, &rng) || !scratch(s, 11, n * 8, &weights) || !scratch(s, 8, 64, &counters))
+        return NNBVH_ERR_DEVICE;
+    int32_t *nCur = (int32_t *)counters, *nNext = nCur + 1;
+    OneRandomState st{(float *)pi, (uint64_t *)rng, (float *)weights};
+    const WavefrontCount cnt{max_items, d_size};
+    const int max_blocks = s->n_cus * 8;
+    if (!hip_ok(hipMemsetAsync(nCur, 0, 4, stream), "reset pass count") ||
+        !hip_ok(launch_or_init(d_p0, d_p1, cnt, st, raysA, (int32_t *)origA, nCur, d_sel_hits, d_sel_rays, max_blocks,
+                               stream), "one-random init launch"))
+        return NNBVH_ERR_DEVICE;
+    int active = 0;
+    if (!read_count(nCur, stream, &active)) return NNBVH_ERR_DEVICE;
+    void *cur = raysA, *next = raysB, *ocur = origA, *onext = origB;
+    for (int pass = 0; active > 0; ++pass) {
+        if (pass > 65536) {
+            set_error("wavefront_intersect_one_random: more than 65536 surfaces on one segment");
+            return NNBVH_ERR_ARG;
+        }
+        int rc = launch(s, 0, cur, active, hits, nullptr, nullptr, nullptr, stream, w, nCur);
+        if (rc != NNBVH_OK) return rc;
+        if (!scratch(s, 9, (size_t)active * sizeof(nnbvh_interaction), &intr)) return NNBVH_ERR_DEVICE;
+        if (!hip_ok(launch_triangle_interactions(m->d, cur, nullptr, hits, active, nCur, intr, m->n_cus * 8, stream),
+                    "interaction kernel launch") ||
+            !hip_ok(hipMemsetAsync(nNext, 0, 4, stream), "reset pass count") ||
+            !hip_ok(launch_or_step(cur, hits, intr, (const int32_t *)ocur, nCur, d_p1, d_material, d_prim_material,
+                                   (long)n_prim_material, st, next, (int32_t *)onext, nNext, d_sel_hits, d_sel_rays,
+                                   active, max_blocks, stream), "one-random step launch"))
+            return NNBVH_ERR_DEVICE;
+        if (!read_count(nNext, stream, &active)) return NNBVH_ERR_DEVICE;
+        std::swap(cur, next);
+        std::swap(ocur, onext);
+        std::swap(nCur, nNext);
+    }
+    if (!hip_ok(launch_or_finish(cnt, st, d_reservoir_pdf, d_weight_sum, max_blocks, stream), "one-random finish launch"))
+        return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
 }
 
 int nnbvh_intersect_closest(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits) {

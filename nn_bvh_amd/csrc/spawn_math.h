@@ -1,0 +1,106 @@
+// spawn_math.h — device restatements of the small reference functions the batched callers need
+// around a trace (all integer / fp32, operation for operation; pinned through the oracle to the
+// compiled reference by tests/test_aux_oracle.py):
+//   Hash / HashFloat / MixBits          util/hash.h:19-128
+//   RNG (PCG32) SetSequence / Uniform   util/rng.h:49-51, 92-99, 130-141
+//   OffsetRayOrigin / SpawnRayTo        ray.h:75-101 (Dot with a Normal3 = FMA + SumOfProducts,
+//                                       util/vecmath.h:1056-1068, util/math.h:577-583)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "trace_math.h"
+
+namespace nnbvh {
+
+DEV uint64_t murmur64a_24(const uint32_t w[6]) {  // MurmurHash64A(key, 24, 0): three 8-byte blocks, no tail
+    const uint64_t m = 0xc6a4a7935bd1e995ull;
+    const int r = 47;
+    uint64_t h = 0ull ^ (24ull * m);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        uint64_t k = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);  // little-endian memcpy
+        k *= m;
+        k ^= k >> r;
+        k *= m;
+        h ^= k;
+        h *= m;
+    }
+    h ^= h >> r;
+    h *= m;
+    h ^= h >> r;
+    return h;
+}
+
+// Hash(Point3f a, Vector3f / Point3f b), hash.h:111-118
+DEV uint64_t hash_6f(V3 a, V3 b) {
+    const uint32_t w[6] = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z),
+                           __float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z)};
+    return murmur64a_24(w);
+}
+DEV float hash_float_6f(V3 a, V3 b) { return (float)(uint32_t)hash_6f(a, b) * 0x1p-32f; }  // hash.h:120-123
+
+DEV uint64_t mix_bits(uint64_t v) {  // hash.h:70-77
+    v ^= (v >> 31);
+    v *= 0x7fb5d329728ea185ull;
+    v ^= (v >> 27);
+    v *= 0x81dadef4bc2dd44dull;
+    v ^= (v >> 33);
+    return v;
+}
+
+struct Pcg32 {
+    uint64_t state, inc;
+};
+DEV uint32_t pcg32_u32(Pcg32 &g) {  // rng.h:92-99
+    const uint64_t oldstate = g.state;
+    g.state = oldstate * 0x5851f42d4c957f2dull + g.inc;
+    const uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+    const uint32_t rot = (uint32_t)(oldstate >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+DEV void pcg32_set_sequence(Pcg32 &g, uint64_t sequenceIndex) {  // rng.h:49-51, 130-136
+    const uint64_t seed = mix_bits(sequenceIndex);
+    g.state = 0u;
+    g.inc = (sequenceIndex << 1u) | 1u;
+    pcg32_u32(g);
+    g.state += seed;
+    pcg32_u32(g);
+}
+DEV float pcg32_float(Pcg32 &g) {  // rng.h:138-141: min(OneMinusEpsilon, u32 * 2^-32)
+    const float v = (float)pcg32_u32(g) * 0x1p-32f;
+    return v < 0x1.fffffep-1f ? v : 0x1.fffffep-1f;
+}
+
+DEV float sop(float a, float b, float c, float d) {  // SumOfProducts, math.h:577-583
+    const float cd = c * d;
+    const float s = __builtin_fmaf(a, b, cd);
+    const float err = __builtin_fmaf(c, d, -cd);
+    return s + err;
+}
+DEV float dot_n(V3 n, V3 v) { return __builtin_fmaf(n.x, v.x, sop(n.y, v.y, n.z, v.z)); }  // vecmath.h:1056-1068
+
+// OffsetRayOrigin(Point3fi pi, Normal3f n, Vector3f w), ray.h:75-92
+DEV V3 offset_ray_origin(V3 lo, V3 hi, V3 n, V3 w) {
+    const V3 err = {(hi.x - lo.x) / 2, (hi.y - lo.y) / 2, (hi.z - lo.z) / 2};  // pi.Error()
+    const V3 an = {__builtin_fabsf(n.x), __builtin_fabsf(n.y), __builtin_fabsf(n.z)};
+    const float d = dot_n(an, err);
+    V3 offset = {d * n.x, d * n.y, d * n.z};
+    if (dot_n(n, w) < 0) offset = {-offset.x, -offset.y, -offset.z};
+    V3 po = {(lo.x + hi.x) / 2 + offset.x, (lo.y + hi.y) / 2 + offset.y, (lo.z + hi.z) / 2 + offset.z};
+    if (offset.x > 0) po.x = next_up(po.x);
+    else if (offset.x < 0) po.x = next_down(po.x);
+    if (offset.y > 0) po.y = next_up(po.y);
+    else if (offset.y < 0) po.y = next_down(po.y);
+    if (offset.z > 0) po.z = next_up(po.z);
+    else if (offset.z < 0) po.z = next_down(po.z);
+    return po;
+}
+
+// SpawnRayTo(Point3fi pFrom, Normal3f n, Float time, Point3f pTo), ray.h:98-101
+DEV void spawn_ray_to(V3 lo, V3 hi, V3 n, V3 pTo, V3 &o, V3 &d) {
+    d = {pTo.x - (lo.x + hi.x) / 2, pTo.y - (lo.y + hi.y) / 2, pTo.z - (lo.z + hi.z) / 2};
+    o = offset_ray_origin(lo, hi, n, d);
+}
+
+}  // namespace nnbvh

@@ -5,8 +5,8 @@ wavefront/aggregate.cpp:34-68), over include/nnbvh.h's nnbvh_wavefront_* entry p
 Queues are device-resident (torch tensors are buffers + the current stream only).  A ray queue is
 the reference's SOA<Ray> (workitems.soa:40-50): six float arrays plus the queue's device-side
 size; the output queues hold indices into the input queue, pushed by the device with the
-reference's rules (wavefront/intersect.h:16-156).  IntersectShadowTr / IntersectOneRandom are
-not provided: they need the media / material systems (see include/nnbvh.h)."""
+reference's rules (wavefront/intersect.h:16-156).  IntersectShadowTr / IntersectOneRandom come in
+their media-free form (see include/nnbvh.h)."""
 import numpy as np
 import torch
 
@@ -123,3 +123,42 @@ class WavefrontAggregate:
             occluded.data_ptr() if occluded is not None else None,
             torch.cuda.current_stream(self.device).cuda_stream),
             "nnbvh_wavefront_intersect_shadow")
+
+    def IntersectShadowTr(self, max_rays, shadow_queue, shading_mesh, Ld, r_u, r_l, pixel_index, L, state=None):
+        """IntersectShadowTr (wavefront/aggregate.cpp:70-88, TraceTransmittance of wavefront/intersect.h:
+        164-274) without media: shadow rays pass through interface surfaces (CLASS_INTERFACE) and are
+        blocked by the first surface with a material; arriving rays add Ld * (1 / (r_u + r_l).Average())
+        to L[pixel_index].  state: optional uint8 [capacity] out (0 arrived, 1 blocked, 2 host)."""
+        assert shadow_queue.tmax is not None, "a shadow queue carries tMax per item"
+        for t in (Ld, r_u, r_l, L):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[-1] == 4
+        assert pixel_index.dtype == torch.int32 and pixel_index.is_contiguous()
+        soa = shadow_queue._wire()
+        pc = self.prim_class
+        check(_lib.lib().nnbvh_wavefront_intersect_shadow_tr(
+            self.aggregate._h, shading_mesh._h, int(max_rays), ptr(soa), shadow_queue.size.data_ptr(),
+            pc.data_ptr() if pc is not None else None, 0 if pc is None else pc.numel(), Ld.data_ptr(),
+            r_u.data_ptr(), r_l.data_ptr(), pixel_index.data_ptr(), L.data_ptr(), L.shape[0],
+            state.data_ptr() if state is not None else None,
+            torch.cuda.current_stream(self.device).cuda_stream), "nnbvh_wavefront_intersect_shadow_tr")
+
+    def IntersectOneRandom(self, max_items, p0, p1, material, shading_mesh, prim_material=None, size=None):
+        """IntersectOneRandom (wavefront/aggregate.cpp:90-116): p0, p1 float32 [n, 3], material int32 [n]
+        device tensors; prim_material int32 per primitive id.  Returns (selected hit records uint8
+        [n, 32], their segment rays uint8 [n, 32], reservoir pdf float32 [n], weight sum float32 [n])."""
+        for t in (p0, p1):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[-1] == 3
+        assert material.dtype == torch.int32 and material.is_contiguous()
+        n = int(max_items)
+        sel_hits = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
+        sel_rays = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
+        pdf = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
+        wsum = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
+        pm = prim_material
+        check(_lib.lib().nnbvh_wavefront_intersect_one_random(
+            self.aggregate._h, shading_mesh._h, n, p0.data_ptr(), p1.data_ptr(), material.data_ptr(),
+            size.data_ptr() if size is not None else None, pm.data_ptr() if pm is not None else None,
+            0 if pm is None else pm.numel(), sel_hits.data_ptr(), sel_rays.data_ptr(), pdf.data_ptr(),
+            wsum.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream),
+            "nnbvh_wavefront_intersect_one_random")
+        return sel_hits, sel_rays, pdf, wsum
