@@ -61,6 +61,19 @@ typedef struct nnbvh_linear_node {
 #define NNBVH_PRIM_INSTANCE 2       /* TransformedPrimitive (cpu/primitive.h:83-101): v[0] = index
                                        into the instance table; top-level tree only */
 
+#define NNBVH_PRIM_ALPHA_TRIANGLE 4  /* a Triangle inside a GeometricPrimitive whose alpha texture is a
+                                       constant (cpu/primitive.cpp:57-70, FloatConstantTexture): v[3] =
+                                       the bit pattern of the float alpha.  A hit is ignored when
+                                       HashFloat(r.o, r.d) > alpha (always when alpha <= 0); the reference
+                                       then re-traces from the hit point against the same shape, which a
+                                       planar triangle cannot be hit by again (shapes_test.cpp:156-206) —
+                                       the device performs that re-test too and, should it ever hit, voids
+                                       the ray like a host-only primitive (instance = -1 / occluded = 2).
+                                       For meshes WITHOUT per-vertex shading normals (the offset normal
+                                       is the geometric one); alpha-tested meshes with normals and
+                                       textured alpha stay NNBVH_PRIM_HOST */
+#define NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED 5 /* same, mesh->reverseOrientation ^ transformSwapsHandedness */
+
 /* One entry of BVHAggregate::primitives: the shape handle flattened to global vertex
  * indices (Triangle{meshIndex,triIndex} -> mesh->vertexIndices[3*tri..], shapes.cpp:326-328). */
 typedef struct nnbvh_prim {

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(kBk) void k_bake_slot_counts(const nnbvh_prim *__re
         c = 4;
         atomicOr(flags, 4);
     } else if (kind == NNBVH_PRIM_HOST) atomicOr(flags, 1);
+    else if (kind == NNBVH_PRIM_ALPHA_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED) atomicOr(flags, 8);
     else if (kind != NNBVH_PRIM_TRIANGLE) atomicOr(flags, 2);  // instances are not baked here
     slots[i] = c;
 }
@@ -82,9 +83,14 @@ __global__ __launch_bounds__(kBk) void k_bake_stream(const nnbvh_prim *__restric
         const float cx = bake_dop(ay, bz, az, by), cy = bake_dop(az, bx, ax, bz), cz = bake_dop(ax, by, ay, bx);
         if (cx * cx + cy * cy + cz * cz == 0.0f) flags |= kPrimDegenerate;
     }
+    float alpha = 0.0f;
+    if (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE || p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED) {
+        flags |= kPrimAlpha | (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED ? kPrimFlipN : 0u);
+        alpha = __int_as_float(p.v[3]);
+    }
     s[0] = make_float4(v[0][0], v[0][1], v[0][2], __int_as_float(p.id));
     s[1] = make_float4(v[1][0], v[1][1], v[1][2], __uint_as_float(flags));
-    s[2] = make_float4(v[2][0], v[2][1], v[2][2], 0);
+    s[2] = make_float4(v[2][0], v[2][1], v[2][2], alpha);
     if (nv == 4) s[3] = make_float4(v[3][0], v[3][1], v[3][2], 0);
 }
 
@@ -212,6 +218,7 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
     std::memcpy(out->bounds + 3, root.pmax, 12);
     out->has_host_prims = flags & 1;
     out->has_patches = (flags & 4) ? 1 : 0;
+    out->has_alpha = (flags & 8) ? 1 : 0;
     return true;
 }
 

@@ -60,6 +60,7 @@ struct BakedScene {
     float bounds[6] = {0, 0, 0, 0, 0, 0};
     int has_host_prims = 0;
     int has_patches = 0;
+    int has_alpha = 0;
 };
 bool bake_on_device(const void *d_nodes, int n_nodes, const void *d_ordered_prims, int n_prims, const void *d_verts,
                     int device, BakedScene *out, std::string *error);

@@ -77,6 +77,7 @@ struct nnbvh_scene {
     int instanced = 0;      // two-level scene: use the INST kernels
     int has_host_prims = 0;
     int has_patches = 1;    // 0: no bilinear patches, the lean kernels (no ray direction parked in LDS) run
+    int has_alpha = 0;      // alpha-tested triangles present: the ALPHA kernels run
     int int_repeat = 3;
     int max_grid_threads = 0;
     double build_ms[1] = {0};  // device build time of nnbvh_scene_create_gpu_build
@@ -218,8 +219,9 @@ static nnbvh_scene *scene_from_baked(const BakedScene &b, int depth, int device)
     std::memcpy(s->bounds, b.bounds, sizeof b.bounds);
     s->root_ref = b.root_ref;
     s->instanced = 0;
-    s->has_host_prims = b.has_host_prims;
-    s->has_patches = b.has_patches;
+    s->has_host_prims = b.has_host_prims | b.has_alpha;
+    s->has_patches = b.has_patches | b.has_alpha;  // the alpha test hashes the ray direction, parked with the patches' one
+    s->has_alpha = b.has_alpha;
     s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
     s->d_wide = (float4 *)b.d_wide;
     s->d_prims = (float4 *)b.d_prims;
@@ -307,7 +309,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     for (int k = 0; k < n_prims; ++k) {
         const nnbvh_prim &p = prims[k];
         int nv, nslots;
-        if (p.kind == NNBVH_PRIM_TRIANGLE) nv = nslots = 3;
+        if (is_triangle_kind(p.kind)) nv = nslots = 3;
         else if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) nv = nslots = 4;
         else if (p.kind == NNBVH_PRIM_HOST) {
             nv = 0;
@@ -347,7 +349,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
                                     : (int32_t) ~(uint32_t)slot_of[(size_t)nodes[i].offset];
     };
     std::vector<float> stream((size_t)n_slots * 4, 0.0f);
-    bool has_host = false;
+    bool has_host = false, has_alpha = false;
     for (int k = 0; k < n_prims; ++k) {
         const nnbvh_prim &p = prims[k];
         float *s = &stream[(size_t)slot_of[(size_t)k] * 4];
@@ -372,10 +374,15 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
             std::memcpy(&s[7], &flags, 4);
             continue;
         }
-        const int nv = p.kind == NNBVH_PRIM_TRIANGLE ? 3 : 4;
+        const int nv = is_triangle_kind(p.kind) ? 3 : 4;
         for (int j = 0; j < nv; ++j) put3(s, 4 * j, verts + 3 * (size_t)p.v[j]);
         if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) flags |= kPrimPatch;
-        if (p.kind == NNBVH_PRIM_TRIANGLE &&
+        if (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE || p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED) {
+            flags |= kPrimAlpha | (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED ? kPrimFlipN : 0u);
+            std::memcpy(&s[11], &p.v[3], 4);  // alpha (float bit pattern) in slot 2's fourth word
+            has_alpha = true;
+        }
+        if (is_triangle_kind(p.kind) &&
             triangle_is_degenerate(verts + 3 * (size_t)p.v[0], verts + 3 * (size_t)p.v[1],
                                    verts + 3 * (size_t)p.v[2]))
             flags |= kPrimDegenerate;
@@ -419,7 +426,8 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     std::memcpy(s->bounds + 3, nodes[0].pmax, 12);
     s->root_ref = ref_of(0);
     s->instanced = n_instances > 0 ? 1 : 0;
-    s->has_host_prims = has_host ? 1 : 0;
+    s->has_host_prims = (has_host || has_alpha) ? 1 : 0;  // an alpha re-trace that hits voids the ray like a host primitive
+    s->has_alpha = has_alpha ? 1 : 0;
     s->has_patches = 1;  // two-level scenes always run the general kernels
     s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
     const size_t wide_bytes = wide.size() * sizeof(WideNode);
@@ -571,7 +579,7 @@ static int grid_blocks(nnbvh_scene *s, int mode) {
     if (per_cu <= 0) {
         TraceParams dummy{};
         int occ = 0;
-        if (launch_trace(mode, dummy, s->window, s->instanced, s->has_patches, 0, nullptr, &occ) != hipSuccess ||
+        if (launch_trace(mode, dummy, s->window, s->instanced, s->has_patches + 2 * s->has_alpha, 0, nullptr, &occ) != hipSuccess ||
             occ <= 0)
             occ = std::max(1, std::min(8, 160 / (s->window * 2)));
         per_cu = occ;
@@ -706,7 +714,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     int blocks = grid_blocks(s, mode);
     const int64_t need = (n + kBlockThreads - 1) / kBlockThreads;
     if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
-    if (!hip_ok(launch_trace(mode, p, s->window, s->instanced, s->has_patches, blocks, stream, nullptr),
+    if (!hip_ok(launch_trace(mode, p, s->window, s->instanced, s->has_patches + 2 * s->has_alpha, blocks, stream, nullptr),
                 "trace kernel launch"))
         return NNBVH_ERR_DEVICE;
     return NNBVH_OK;

@@ -37,7 +37,8 @@ struct TraceParams {
 hipError_t launch_zero_queue(unsigned *queue, int words, hipStream_t stream);
 
 // occupancy != nullptr: do not launch, report resident blocks per CU of that kernel instance
-// patches = 0: the scene holds no bilinear patches (kernel instances without the parked ray direction)
+// patches: bit 0 = the scene holds bilinear patches (0: kernel instances without the parked ray direction),
+// bit 1 = it holds alpha-tested triangles (the ALPHA kernel instances)
 hipError_t launch_trace(int mode, const TraceParams &p, int window, int instanced, int patches, int blocks,
                         hipStream_t stream, int *occupancy);
 

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "bvh_trace.h"
+#include "spawn_math.h"
 #include "trace_math.h"
 
 namespace nnbvh {
@@ -67,10 +68,13 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 // PATCH = 0: the scene holds no bilinear patches and no instances, so nothing ever reads the ray
 // direction after the ray is fetched; it is not parked in LDS (3 fields = 3 KiB per block less:
 // 22 KiB, which lets a seventh block share the CU's 160 KiB).
-template <int MODE, int W, int INST, int PATCH>
+// ALPHA = 1: the scene holds alpha-tested triangles (kPrimAlpha, cpu/primitive.cpp:57-70); compiled
+// separately so that other scenes pay nothing for the hash and the re-trace.
+template <int MODE, int W, int INST, int PATCH, int ALPHA = 0>
 __global__ __launch_bounds__(kBlockThreads, (INST ? 1 : (MODE == 0 ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY) + (PATCH ? 0 : NNBVH_LEAN_EXTRA_WAVES)))
 void trace_kernel(TraceParams p) {
     static_assert(PATCH || !INST, "two-level scenes need the ray direction");
+    static_assert(PATCH || !ALPHA, "the alpha test hashes the ray direction");
     __shared__ int s_ref[kBlockThreads / 64][W][64];
     __shared__ float s_key[kBlockThreads / 64][W][64];
     // Cold per-ray state parked in LDS ([field][lane], conflict-free) instead of VGPRs: the
@@ -356,6 +360,32 @@ void trace_kernel(TraceParams p) {
                                                 {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
                                                 {s2.x, s2.y, s2.z}, x0, x1, x2, th);
                             next = slot + 3;
+                            if (ALPHA && hit && (flags & kPrimAlpha)) {
+                                // GeometricPrimitive::Intersect, cpu/primitive.cpp:57-70 (IntersectP takes
+                                // the same route, :79-81): stochastic alpha test on the ray as given
+                                const float a = s2.w;
+                                if (a < 1) {
+                                    const V3 rd = {cold[kColdD][lane], cold[kColdD + 1][lane],
+                                                   cold[kColdD + 2][lane]};
+                                    const float u = (a <= 0) ? 1.f : hash_float_6f(r.o, rd);
+                                    if (u > a) {
+                                        // ignored; the reference re-traces from the hit point against this
+                                        // shape alone: rNext = si->intr.SpawnRay(r.d), Intersect(rNext, tMax - tHit)
+                                        hit = false;
+                                        RayState rn = r;  // same direction: same reciprocals and shear
+                                        rn.o = alpha_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                                                    {s2.x, s2.y, s2.z}, x0, x1, x2,
+                                                                    (flags & kPrimFlipN) != 0, rd);
+                                        tests += 1;  // Triangle::Intersect counts the re-test too
+                                        float y0, y1, y2, tn;
+                                        if (triangle_test(rn, tMax - th, (flags & kPrimDegenerate) != 0,
+                                                          {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                                          {s2.x, s2.y, s2.z}, y0, y1, y2, tn))
+                                            cold[kColdHost][lane] = 1.0f;  // never for a planar triangle; if
+                                                                           // it happens the ray is the caller's
+                                    }
+                                }
+                            }
                         } else {
                             const float4 s3 = p.prims[slot + 3];
                             x2 = 0.0f;
@@ -437,13 +467,13 @@ void trace_kernel(TraceParams p) {
 }
 
 // ------------------------------------------------------------------------------------
-template <int MODE, int W, int INST, int PATCH>
+template <int MODE, int W, int INST, int PATCH, int ALPHA = 0>
 static hipError_t launch_one(const TraceParams &p, int blocks, hipStream_t stream, int *occupancy) {
     if (occupancy) {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, trace_kernel<MODE, W, INST, PATCH>,
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, trace_kernel<MODE, W, INST, PATCH, ALPHA>,
                                                             kBlockThreads, 0);
     }
-    hipLaunchKernelGGL((trace_kernel<MODE, W, INST, PATCH>), dim3((unsigned)blocks), dim3(kBlockThreads), 0,
+    hipLaunchKernelGGL((trace_kernel<MODE, W, INST, PATCH, ALPHA>), dim3((unsigned)blocks), dim3(kBlockThreads), 0,
                        stream, p);
     return hipGetLastError();
 }
@@ -451,7 +481,9 @@ static hipError_t launch_one(const TraceParams &p, int blocks, hipStream_t strea
 template <int MODE>
 static hipError_t launch_mode(const TraceParams &p, int window, int instanced, int patches, int blocks,
                               hipStream_t stream, int *occupancy) {
-    // two-level scenes: one instance of the kernel (window 8)
+    // scenes with alpha-tested triangles and two-level scenes: one instance of the kernel each (window 8)
+    if (patches & 2) return instanced ? launch_one<MODE, 8, 1, 1, 1>(p, blocks, stream, occupancy)
+                                      : launch_one<MODE, 8, 0, 1, 1>(p, blocks, stream, occupancy);
     if (instanced) return launch_one<MODE, 8, 1, 1>(p, blocks, stream, occupancy);
     if (!patches && window == 8) return launch_one<MODE, 8, 0, 0>(p, blocks, stream, occupancy);
     switch (window) {

@@ -3,6 +3,8 @@
 #include <cstdint>
 #include <string>
 
+#include "../../include/nnbvh.h"
+
 namespace nnbvh {
 
 void set_error(const std::string &msg);
@@ -42,6 +44,14 @@ constexpr uint32_t kPrimDegenerate = 4u;
 constexpr uint32_t kPrimInstance = 8u;
 // host-only primitive (3 slots, no geometry): {0,0,0,id} {0,0,0,flags} {0,0,0,0}
 constexpr uint32_t kPrimHost = 16u;
+
+// alpha-tested triangle (GeometricPrimitive with a constant alpha, cpu/primitive.cpp:57-70): slot 2's
+// fourth word holds alpha; kPrimFlipN = mesh->reverseOrientation ^ mesh->transformSwapsHandedness
+constexpr uint32_t kPrimAlpha = 32u;
+constexpr uint32_t kPrimFlipN = 64u;
+inline bool is_triangle_kind(int kind) {
+    return kind == NNBVH_PRIM_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED;
+}
 
 constexpr int kMaxStack = 64;  // the reference's nodesToVisit[64], aggregates.cpp:538
 

@@ -103,4 +103,29 @@ DEV void spawn_ray_to(V3 lo, V3 hi, V3 n, V3 pTo, V3 &o, V3 &d) {
     o = offset_ray_origin(lo, hi, n, d);
 }
 
+// Origin of the ray GeometricPrimitive::Intersect traces on after an alpha-rejected triangle hit
+// (cpu/primitive.cpp:64-66: rNext = si->intr.SpawnRay(r.d)) for a triangle of a mesh WITHOUT
+// per-vertex shading normals: Triangle::InteractionFromIntersection (shapes.h:884-1010) gives
+//   pHit = b0 p0 + b1 p1 + b2 p2, pError = gamma(7) (|b0 p0| + |b1 p1| + |b2 p2|), pi = Point3fi(pHit, pError)
+//   n = Normalize(Cross(p0 - p2, p1 - p2)), negated under reverseOrientation ^ transformSwapsHandedness
+// and Interaction::SpawnRay(d) = OffsetRayOrigin(pi, n, d) (interaction.h:98-100, ray.h:75-92).
+DEV V3 alpha_retrace_origin(V3 p0, V3 p1, V3 p2, float b0, float b1, float b2, bool flip, V3 d) {
+    constexpr float g7 = gamma_f(7);
+    const V3 ph = {(b0 * p0.x + b1 * p1.x) + b2 * p2.x, (b0 * p0.y + b1 * p1.y) + b2 * p2.y,
+                   (b0 * p0.z + b1 * p1.z) + b2 * p2.z};
+    const V3 pe = {g7 * ((__builtin_fabsf(b0 * p0.x) + __builtin_fabsf(b1 * p1.x)) + __builtin_fabsf(b2 * p2.x)),
+                   g7 * ((__builtin_fabsf(b0 * p0.y) + __builtin_fabsf(b1 * p1.y)) + __builtin_fabsf(b2 * p2.y)),
+                   g7 * ((__builtin_fabsf(b0 * p0.z) + __builtin_fabsf(b1 * p1.z)) + __builtin_fabsf(b2 * p2.z))};
+    // Point3fi(pHit, pError): Interval::FromValueAndError per component (math.h:829-838)
+    const V3 lo = {pe.x == 0 ? ph.x : next_down(ph.x + (-pe.x)), pe.y == 0 ? ph.y : next_down(ph.y + (-pe.y)),
+                   pe.z == 0 ? ph.z : next_down(ph.z + (-pe.z))};
+    const V3 hi = {pe.x == 0 ? ph.x : next_up(ph.x + pe.x), pe.y == 0 ? ph.y : next_up(ph.y + pe.y),
+                   pe.z == 0 ? ph.z : next_up(ph.z + pe.z)};
+    const V3 c = cross(sub(p0, p2), sub(p1, p2));
+    const float len = __builtin_sqrtf(len2(c));  // Normalize: v / Length(v)
+    V3 n = {c.x / len, c.y / len, c.z / len};
+    if (flip) n = {-n.x, -n.y, -n.z};
+    return offset_ray_origin(lo, hi, n, d);
+}
+
 }  // namespace nnbvh

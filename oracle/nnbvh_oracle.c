@@ -443,7 +443,7 @@ void orc_transform_bounds(const float m[12], const float in[6], float out[6]) {
 /* ---- primitive dispatch (cpu/primitive.cpp:24-32 -> shapes.cpp:320-358, 1131-1156) --- */
 static inline int prim_test(const orc_prim *p, const float *verts, const float o[3],
                             const float d[3], float tmax, float res[4]) {
-    if (p->kind == 0) {
+    if (p->kind == 0 || p->kind == 4 || p->kind == 5) {
         return orc_triangle(o, d, tmax, verts + 3 * (size_t)p->v[0], verts + 3 * (size_t)p->v[1],
                             verts + 3 * (size_t)p->v[2], res);
     } else {
@@ -458,6 +458,44 @@ static inline int prim_test(const orc_prim *p, const float *verts, const float o
         res[3] = uvt[2];
         return 1;
     }
+}
+
+/* ---- GeometricPrimitive::Intersect with a constant alpha, cpu/primitive.cpp:50-77 ------------- */
+/* prim kinds 4 / 5: a triangle (mesh without per-vertex normals; 5 = flipped orientation) behind a
+ * GeometricPrimitive whose alpha texture evaluates to the constant in v[3] (float bit pattern).
+ * Every Triangle::Intersect call counts in nTriTests, the recursive ones too. */
+int orc_triangle_interaction(const float p9[9], const float *uv6, const float *n9, const float *s9,
+                             int flip_normal, const float b[3], const float wo[3], float time,
+                             int face_index, float out[44]);
+uint64_t orc_hash_6f(const float a[3], const float b[3]);
+float orc_hash_float_6f(const float a[3], const float b[3]);
+void orc_offset_ray_origin(const float lo[3], const float hi[3], const float n[3], const float w[3], float po[3]);
+
+static int alpha_intersect(const orc_prim *p, const float *verts, const float o[3], const float d[3],
+                           float tmax, float res[4], int *tests) {
+    float r[4];
+    ++*tests;
+    if (!prim_test(p, verts, o, d, tmax, r)) return 0; /* :52-54 */
+    float a;
+    memcpy(&a, &p->v[3], 4);
+    if (a < 1) { /* :58 */
+        const float u = (a <= 0) ? 1.f : orc_hash_float_6f(o, d); /* :60 */
+        if (u > a) {
+            /* :63-69 ignore this intersection and trace a new ray: rNext = si->intr.SpawnRay(r.d) */
+            float p9[9], wo[3] = {-d[0], -d[1], -d[2]}, rec[44], on[3], rn[4];
+            memcpy(p9, verts + 3 * (size_t)p->v[0], 12);
+            memcpy(p9 + 3, verts + 3 * (size_t)p->v[1], 12);
+            memcpy(p9 + 6, verts + 3 * (size_t)p->v[2], 12);
+            orc_triangle_interaction(p9, NULL, NULL, NULL, p->kind == 5, r, wo, 0.0f, 0, rec);
+            orc_offset_ray_origin(rec + 38, rec + 41, rec + 11, d, on);
+            if (!alpha_intersect(p, verts, on, d, tmax - r[3], rn, tests)) return 0;
+            rn[3] += r[3]; /* siNext->tHit += si->tHit */
+            memcpy(res, rn, 16);
+            return 1;
+        }
+    }
+    memcpy(res, r, 16);
+    return 1;
 }
 
 /* ---- BVHAggregate::Intersect, aggregates.cpp:529-579 -------------------------------- */
@@ -500,8 +538,14 @@ static void closest_tree(const orc_node *nodes, const orc_prim *prims, const flo
                         }
                         continue;
                     }
-                    ++tests;
-                    if (prim_test(p, verts, o, d, tmax, r)) {
+                    int primHit;
+                    if (p->kind == 4 || p->kind == 5) {
+                        primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests);
+                    } else {
+                        ++tests;
+                        primHit = prim_test(p, verts, o, d, tmax, r);
+                    }
+                    if (primHit) {
                         hit->prim = p->id;
                         hit->b0 = r[0];
                         hit->b1 = r[1];
@@ -580,8 +624,14 @@ static int any_tree(const orc_node *nodes, const orc_prim *prims, const float *v
                         }
                         continue;
                     }
-                    ++tests;
-                    if (prim_test(p, verts, o, d, tmax, r)) {
+                    int primHit; /* GeometricPrimitive::IntersectP with alpha = Intersect(...).has_value(), :79-81 */
+                    if (p->kind == 4 || p->kind == 5) {
+                        primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests);
+                    } else {
+                        ++tests;
+                        primHit = prim_test(p, verts, o, d, tmax, r);
+                    }
+                    if (primHit) {
                         found = 1;
                         goto done;
                     }

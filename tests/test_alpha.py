@@ -1,0 +1,106 @@
+"""Alpha-tested GeometricPrimitive with a constant alpha (cpu/primitive.cpp:50-84) as primitive kinds
+NNBVH_PRIM_ALPHA_TRIANGLE / _FLIPPED: the oracle's restatement (HashFloat, SpawnRay and the interaction
+it offsets from are each pinned to the compiled reference) and the device kernels against it."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenes_small as ss
+from nn_bvh_amd import build_tree, scene
+
+
+def alpha_scene(seed=4, n=3000):
+    verts, prims = ss.random_soup(n, 0, seed, extent=6.0, size=1.2)
+    rng = np.random.default_rng(seed + 1)
+    prims = prims.copy()
+    alpha = rng.choice(np.array([0.0, 0.25, 0.5, 0.9, 1.0, 1.5, -0.5], np.float32), len(prims))
+    kinds = rng.choice(np.array([0, 4, 5], np.int32), len(prims), p=[0.3, 0.4, 0.3])
+    prims["kind"] = kinds
+    prims["v"][:, 3] = np.where(kinds == 0, 0, alpha.view(np.int32))
+    return verts, prims, alpha, kinds
+
+
+def test_oracle_alpha_semantics():
+    verts, prims, alpha, kinds = alpha_scene()
+    tree = build_tree(prims, verts)
+    rays = scene.random_rays(20000, verts.min(0) - 1, verts.max(0) + 1, 7)
+    h = ob.closest(tree.nodes, tree.ordered_prims, verts, rays)
+    # alpha >= 1 everywhere = plain triangles
+    plain = prims.copy()
+    plain["kind"] = 0
+    plain["v"][:, 3] = 0
+    tp = build_tree(plain, verts)
+    assert tp.nodes.tobytes() == tree.nodes.tobytes()  # kinds 4 / 5 build like triangles
+    hp = ob.closest(tp.nodes, tp.ordered_prims, verts, rays)
+    opaque = prims.copy()
+    opaque["v"][:, 3] = np.where(kinds == 0, 0, np.float32(1.0).view(np.int32))
+    to = build_tree(opaque, verts)
+    assert ob.closest(to.nodes, to.ordered_prims, verts, rays).tobytes() == hp.tobytes()
+    # alpha <= 0 primitives are never hit; fully transparent set = scene without them (up to the extra re-tests)
+    clear = prims.copy()
+    clear["v"][:, 3] = np.where(kinds == 0, 0, np.float32(0.0).view(np.int32))
+    tc = build_tree(clear, verts)
+    hc = ob.closest(tc.nodes, tc.ordered_prims, verts, rays)
+    assert (kinds[np.maximum(hc["prim"], 0)][hc["prim"] >= 0] == 0).all()
+    only = build_tree(plain[kinds == 0], verts)
+    ho = ob.closest(only.nodes, only.ordered_prims, verts, rays)
+    assert np.array_equal(hc["prim"], ho["prim"]) and np.array_equal(hc["t"].view(np.uint32), ho["t"].view(np.uint32))
+    # the stochastic cases: some hits on 0 < alpha < 1 primitives survive, some do not
+    mid = (alpha > 0) & (alpha < 1) & (kinds != 0)
+    hit_mid = (h["prim"] >= 0) & mid[np.maximum(h["prim"], 0)]
+    was_mid = (hp["prim"] >= 0) & mid[np.maximum(hp["prim"], 0)]
+    assert 0.2 * was_mid.sum() < hit_mid.sum() < was_mid.sum()
+    # any-hit follows Intersect(...).has_value()
+    occ, _, _ = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays)
+    assert np.array_equal(occ == 1, h["prim"] >= 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["host_tree", "device_build"])
+def test_device_alpha_equals_oracle(how):
+    from nn_bvh_amd import BVHAggregate
+    verts, prims, alpha, kinds = alpha_scene(9, 5000)
+    tree = build_tree(prims, verts)
+    rays = np.concatenate([scene.random_rays(60000, verts.min(0) - 1, verts.max(0) + 1, 8),
+                           scene.random_rays(10000, verts.min(0), verts.max(0), 10, tmax=0.6)])
+    if how == "host_tree":
+        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+    else:
+        agg = BVHAggregate.build_on_device(prims, verts, 4, "sah")
+    got = agg.Intersect(rays)
+    exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, 4)
+    void = got["instance"] == -1   # an alpha re-trace that hit: never for planar triangles
+    assert void.sum() == 0
+    assert got.tobytes() == exp.tobytes()
+    assert (kinds[np.maximum(exp["prim"], 0)][exp["prim"] >= 0] != 0).mean() > 0.3
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    eo, ev, et = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, 4)
+    assert np.array_equal(occ, eo) and np.array_equal(vis, ev) and np.array_equal(tst, et)
+    assert np.array_equal(agg.IntersectP(rays), eo)
+    agg.close()
+
+
+@pytest.mark.gpu
+def test_device_alpha_inside_instances():
+    """the alpha test hashes the ray the primitive is given: inside an instance, the instance-space ray"""
+    from nn_bvh_amd import BVHAggregate, instancing
+    from test_oracle_vs_reference_live import random_affine
+    verts, prims, alpha, kinds = alpha_scene(12, 800)
+    rng = np.random.default_rng(3)
+    n_place = 6
+    M, _ = random_affine(rng, n_place)
+    M[:, :3, 3] = rng.uniform(-15, 15, size=(n_place, 3))
+    Mi = np.linalg.inv(M.astype(np.float64)).astype(np.float32)
+    placements = [(0, M[j, :3].reshape(12), Mi[j, :3].reshape(12)) for j in range(n_place)]
+    top = prims[:0]
+    nodes, aprims, instances, n_top = instancing.assemble_two_level(top, verts, [prims], placements)
+    agg = BVHAggregate.from_tree(nodes, aprims, verts, instances=instances, n_top_nodes=n_top)
+    rays = scene.random_rays(40000, [-25, -25, -25], [25, 25, 25], 13)
+    got = agg.Intersect(rays)
+    exp = ob.closest_inst(nodes, aprims, verts, instances, rays, 4)
+    assert (got["instance"] == -1).sum() == 0 and got.tobytes() == exp.tobytes()
+    assert (got["instance"] > 0).mean() > 0.1
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    eo, ev, et = ob.any_hit_inst(nodes, aprims, verts, instances, rays, 4)
+    assert np.array_equal(occ, eo) and np.array_equal(vis, ev) and np.array_equal(tst, et)
+    agg.close()
