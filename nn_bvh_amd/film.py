@@ -88,3 +88,22 @@ class Film:
             if r != rank:
                 self.unpack(index_lists[r], int(index_lists[r].numel()), out[r], stream)
         return width * 32
+
+
+def pixel_rgb(pixels):
+    """RGBFilm::GetPixelRGB (film.h:257-275) without splats and with an identity output transform:
+    rgb = Float(rgbSum) / Float(weightSum) where the weight is non-zero.  pixels: float64 [n, 4]."""
+    rgb = pixels[:, :3].astype(np.float32)
+    w = pixels[:, 3].astype(np.float32)
+    nz = w != 0
+    rgb[nz] = rgb[nz] / w[nz, None]
+    return rgb
+
+
+def write_pfm(path, rgb, xres, yres):
+    """Portable float map (the format pbrt's imgtool reads, util/image.cpp): rows bottom-up,
+    little-endian float32."""
+    img = np.asarray(rgb, np.float32).reshape(yres, xres, 3)[::-1]
+    with open(path, "wb") as f:
+        f.write(f"PF\n{xres} {yres}\n-1.0\n".encode())
+        f.write(np.ascontiguousarray(img, "<f4").tobytes())

@@ -339,3 +339,65 @@ def random_rays(n, lo, hi, seed=5, tmax=np.inf):
     rays["d"] = (b - a).astype(np.float32)
     rays["tmax"] = tmax
     return rays
+
+
+# ---- text ingestion: pbrt `Shape "trianglemesh"` blocks and Wavefront .obj ----------------------
+def read_pbrt_trianglemeshes(path):
+    """Triangle meshes of a pbrt scene text file: every `"integer indices" [ ... ]` list with its
+    `"point3 P" [ ... ]` list (also the v3 spelling `"point P"`), concatenated into one vertex / index
+    array with the indices rebased — the geometry machine_learning/nn_parser.py:6-98
+    (parse_pbrt_file_with_meshes) extracts, without its one-statement-per-line restrictions.
+    Comments (# ...) are dropped.  Returns (verts float32 [n, 3], tris int32 [m, 3], mesh_of_tri
+    int32 [m]); transforms (CTM) are NOT applied: like the reference parser this reads object-space
+    coordinates (the shipped benchmark scenes carry only camera transforms)."""
+    import re
+    text = open(path, "r").read()
+    text = re.sub(r"#[^\n]*", " ", text)
+    lists = re.findall(r'"(integer\s+indices|point3\s+P|point\s+P)"\s*\[([^\]]*)\]', text)
+    verts, tris, mesh_of = [], [], []
+    pending_idx, pending_p, base, mesh = None, None, 0, 0
+    for name, body in lists:
+        if name.startswith("integer"):
+            pending_idx = np.array(body.split(), np.int64)
+        else:
+            pending_p = np.array(body.split(), np.float64).astype(np.float32)
+        if pending_idx is not None and pending_p is not None:
+            if len(pending_idx) % 3 or len(pending_p) % 3:
+                raise ValueError(f"{path}: trianglemesh {mesh}: index / coordinate count not a multiple of 3")
+            p = pending_p.reshape(-1, 3)
+            t = pending_idx.reshape(-1, 3)
+            if len(t) and (t.min() < 0 or t.max() >= len(p)):
+                raise ValueError(f"{path}: trianglemesh {mesh}: vertex index out of range")
+            verts.append(p)
+            tris.append((t + base).astype(np.int32))
+            mesh_of.append(np.full(len(t), mesh, np.int32))
+            base += len(p)
+            mesh += 1
+            pending_idx = pending_p = None
+    if not verts:
+        return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), np.zeros(0, np.int32)
+    return np.concatenate(verts), np.concatenate(tris), np.concatenate(mesh_of)
+
+
+def read_obj(path):
+    """Wavefront .obj as machine_learning/nn_parser.py:130-166 (parse_obj_file_with_meshes) reads it:
+    `v x y z` vertices, `f a/.. b/.. c/..` faces (first three corners; 1-based), `g` starts a new mesh.
+    Returns (verts float32 [n, 3], tris int32 [m, 3], mesh_of_tri int32 [m])."""
+    verts, tris, mesh_of, mesh = [], [], [], 0
+    with open(path, "r") as f:
+        for line in f:
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "v":
+                verts.append([float(tok[1]), float(tok[2]), float(tok[3])])
+            elif tok[0] == "f":
+                tris.append([int(tok[k].split("/")[0]) - 1 for k in (1, 2, 3)])
+                mesh_of.append(mesh)
+            elif tok[0] == "g":
+                mesh += 1
+    verts = np.array(verts, np.float32).reshape(-1, 3)
+    tris = np.array(tris, np.int32).reshape(-1, 3)
+    if len(tris) and (tris.min() < 0 or tris.max() >= len(verts)):
+        raise ValueError(f"{path}: face index out of range")
+    return verts, tris, np.array(mesh_of, np.int32)
