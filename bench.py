@@ -88,10 +88,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wavefront", action="store_true",
                     help="also time the step through the wavefront-queue entry points")
+    ap.add_argument("--serial", action="store_true",
+                    help="trace the three batches of a step as three launches (round-1 behaviour) instead "
+                         "of one nnbvh_trace_batches_device call = ONE launch over all three")
     ap.add_argument("--overlapped", action="store_true",
-                    help="also time the step as one nnbvh_trace_batches_device call (concurrent "
-                         "launches; off by default so that a rocprofv3 kernel average of this "
-                         "command equals roofline.avg_launch_ms)")
+                    help="also time the step with the three batches as concurrent launches on the "
+                         "library's internal streams (fused_batches off)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="rays per class timed on the host cores for cpu_baseline")
     ap.add_argument("--cpu-passes", type=int, default=5)
@@ -138,17 +140,17 @@ def dry_run(args, rank, world):
     return 0
 
 
-def profile_counters():
-    """VALU-issue figures of the closest-hit kernel from the newest committed rocprofv3 PMC summary
-    (profiles/r*_final*/summary.json; collected as MI355X_MICROARCH.md prescribes, separate --pmc
-    passes of this same command).  None if no summary is present."""
+def profile_counters(prefix="trace_kernel<0"):
+    """VALU-issue figures of the dominant kernel (name prefix) from the newest committed rocprofv3 PMC
+    summary that holds it (profiles/r*_final*/summary.json; collected as MI355X_MICROARCH.md
+    prescribes, separate --pmc passes of this same command).  None if no summary is present."""
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final*", "summary.json")))
     for path in reversed(paths):
         try:
             summ = json.load(open(path))
-            name = next(k for k in summ["counters_per_launch_mean"] if k.startswith("trace_kernel<0"))
+            name = next(k for k in summ["counters_per_launch_mean"] if k.startswith(prefix))
             c = summ["counters_per_launch_mean"][name]
-            ks = next(k for k in summ["kernel_stats"] if "trace_kernel<0" in k["Name"])
+            ks = next(k for k in summ["kernel_stats"] if prefix in k["Name"])
             cycles = float(ks["AverageNs"]) * SHADER_GHZ
             return {
                 "source": os.path.relpath(path, ROOT),
@@ -330,7 +332,14 @@ def main():
         # film.h:95-100, is the caller's); slot i of every pass is pixel mine[i]
         film.add_samples_device(d_px, d_py, st["d_L"], st["d_w"], n_slots, passes, rgb_stride=4, stream=stream)
 
+    fused = not args.serial and kd is None
+
     def trace_stage(st):
+        if fused:  # one launch: the wavefronts drain primary, bounce and shadow rays one batch after the other
+            agg.trace_batches_device([("closest", st["d_primary"].data_ptr(), st["n_primary"], st["d_hits"].data_ptr()),
+                                      ("closest", st["d_bounce"].data_ptr(), st["n_bounce"], st["d_bhits"].data_ptr()),
+                                      ("any", st["d_shadow"].data_ptr(), st["n_shadow"], st["d_occ"].data_ptr())], stream)
+            return
         agg.intersect_device(st["d_primary"].data_ptr(), st["d_hits"].data_ptr(), st["n_primary"], stream)
         agg.intersect_device(st["d_bounce"].data_ptr(), st["d_bhits"].data_ptr(), st["n_bounce"], stream)
         agg.intersect_p_device(st["d_shadow"].data_ptr(), st["d_occ"].data_ptr(), st["n_shadow"], stream=stream)
@@ -433,6 +442,22 @@ def main():
     bytes_closest = alg_bytes(hits) + alg_bytes(bhits)          # both launches of the kernel
     ms_closest = ms_primary + ms_bounce
     achieved = bytes_closest / (ms_closest * 1e-3) / 1e9         # GB/s over the kernel's launches
+    roof_kernel = "kd_trace_kernel<closest>" if kd is not None else "trace_kernel<closest>"
+    roof_bytes_per_launch, roof_ms = bytes_closest / 2, ms_closest / 2
+    if fused:
+        # the dominant kernel is the one launch of a step: trace_kernel<3> over all three batches.  Its
+        # algorithmic bytes add the shadow rays' 36 + 32 V + 48 T (V, T from a counting any-hit launch)
+        d_v = torch.empty(n_shadow, dtype=torch.int32, device=cdev)
+        d_t = torch.empty(n_shadow, dtype=torch.int32, device=cdev)
+        agg.intersect_p_device(s0["d_shadow"].data_ptr(), s0["d_occ"].data_ptr(), n_shadow, d_v.data_ptr(),
+                               d_t.data_ptr(), stream)
+        torch.cuda.synchronize()
+        bytes_shadow = 36.0 * n_shadow + node_bytes * float(d_v.sum(dtype=torch.int64).item()) + \
+            prim_bytes * float(d_t.sum(dtype=torch.int64).item())
+        ms_fused = time_kernel(lambda: trace_stage(s0), reps)
+        roof_kernel = "trace_kernel<3> (one launch: primary + bounce closest-hit, shadow any-hit)"
+        roof_bytes_per_launch, roof_ms = bytes_closest + bytes_shadow, ms_fused
+        achieved = roof_bytes_per_launch / (roof_ms * 1e-3) / 1e9
 
     # ---- the same step through nnbvh_trace_batches_device: the three batches run concurrently
     # on the library's internal streams, so each launch's drain overlaps the others' work.
@@ -443,6 +468,7 @@ def main():
 
     overlapped_s = None
     if args.overlapped:
+        agg.set_option("fused_batches", 0)
         step_overlapped()
         barrier()
         t1 = time.perf_counter()
@@ -450,6 +476,7 @@ def main():
             step_overlapped()
         barrier()
         overlapped_s = max_over_ranks(time.perf_counter() - t1)
+        agg.set_option("fused_batches", 1)
 
     # ---- the same step through the wavefront-queue entry points (SOA ray queues with
     # device-side sizes in, index queues and pixel radiance out): opt-in, reported next to `value`
@@ -506,7 +533,7 @@ def main():
     # What binds the kernel, from the committed rocprofv3 PMC passes of this same command
     # (profiles/; collected and corrected as MI355X_MICROARCH.md §HBM prescribes).  Only quoted when
     # the profile was taken at the same --spp on crown at N=1.
-    prof = profile_counters()
+    prof = profile_counters("trace_kernel<3" if fused else "trace_kernel<0")
     if prof is not None and not (prof.get("spp") in (None, args.spp) and args.scene == "crown" and world == 1 and kd is None):
         prof = None
     traffic = prof["hbm_bytes_per_launch"] if prof else None
@@ -546,6 +573,7 @@ def main():
                 "rays_shadow": int(n_shadow),
                 "rays_per_step_per_gpu": int(rays_per_step),
                 "parallelism": f"tile-sharded x{world}, BVH replicated, film all-gather after the pass",
+                "launches_per_step": "1 (nnbvh_trace_batches_device, mode-3 kernel)" if fused else "3",
             },
             "per_class_mrays": {
                 "primary_closest": round(n_primary / ms_primary / 1e3, 2),
@@ -566,17 +594,17 @@ def main():
                 # limiter the counters show and `valu_issue` / `hbm_physical` quantify it.
                 "bound": "hbm",
                 "label": "alg_hbm",
-                "kernel": "kd_trace_kernel<closest>" if kd is not None else "trace_kernel<closest>",
+                "kernel": roof_kernel,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "alg_bytes_per_launch": round(bytes_closest / 2),
+                "alg_bytes_per_launch": round(roof_bytes_per_launch),
                 "alg_bytes_per_ray": round(bytes_closest / (len(hits) + len(bhits)), 1),
                 "mean_nodes_visited": round(float(hits["nodes_visited"].mean()), 2),
                 "mean_prim_tests": round(float(hits["prim_tests"].mean()), 2),
-                "avg_launch_ms": round(ms_closest / 2, 4),
+                "avg_launch_ms": round(roof_ms, 4),
                 "binding": "valu_issue",
                 "valu_issue": None if prof is None else {
                     "frac": prof["frac"], "lanes_per_valu": prof["lanes_per_valu"],
@@ -599,7 +627,7 @@ def main():
                 "value": round(rays_per_step * world * args.steps / overlapped_s / 1e6, 2),
                 "unit": "Mray/s",
                 "ms_per_step": round(overlapped_s / args.steps * 1e3, 4),
-                "how": "the three traces of sample set 0 as one nnbvh_trace_batches_device call (concurrent)",
+                "how": "the three traces of sample set 0 as concurrent launches on internal streams",
             }
         if wavefront_s is not None:
             result["wavefront_queues"] = {

@@ -205,10 +205,12 @@ int nnbvh_intersect_any_device(nnbvh_scene *s, const void *d_rays, int64_t n, vo
 /* ---- several independent batches at once --------------------------------------------------
  * One call traces n_batches independent ray batches (e.g. the closest-hit queue and the
  * shadow-ray queue of one wavefront iteration: wavefront/integrator.cpp:403-406 and :575-579
- * are independent of each other).  The batches run concurrently on internal streams that are
- * forked from and joined back into `stream`, so to the caller the call is ONE asynchronous
- * operation on `stream`; a launch's tail (the dependent chain of its longest ray) then
- * overlaps the other batches' work instead of idling the GPU. */
+ * are independent of each other).  Up to 4 batches of fewer than 2^28 rays each, closest-hit or
+ * any-hit without counts, are traced by ONE kernel launch on `stream` (the persistent wavefronts
+ * drain the batches one after the other, so the call pays one ramp-up and one drain — the
+ * dependent chain of its longest ray — instead of one per batch).  Other
+ * combinations run concurrently on internal streams forked from and joined back into `stream`.
+ * Either way the call is ONE asynchronous operation on `stream`. */
 #define NNBVH_BATCH_CLOSEST 0
 #define NNBVH_BATCH_ANY 1
 typedef struct nnbvh_batch {
@@ -464,11 +466,11 @@ int nnbvh_kd_intersect_any_device(nnbvh_kd_scene *s, const void *d_rays, int64_t
                                   void *d_nodes_visited, void *d_prim_tests, void *stream);
 
 /* tuning knobs (speed only, never results): "stack_window" (LDS entries per lane: 4, 8, 16),
- * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "prim_weight" / "refill_weight" (1..64:
- * how much a lane waiting on a primitive test / an idle lane counts against a lane waiting on
- * an interior node, which counts 16, when a wavefront picks its next step), "int_repeat" (1..16 interior steps per scheduling
- * decision).  Returns
- * NNBVH_ERR_ARG for unknown keys. */
+ * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "prim_weight" / "refill_weight" (1..64: how much a
+ * lane waiting on a primitive test / an idle lane counts against a lane waiting on an interior node,
+ * which counts 16, when a wavefront picks its next step), "int_repeat" (1..16 interior steps per
+ * scheduling decision), "fused_batches" (0/1: nnbvh_trace_batches_device as one launch where the
+ * batches allow it).  Returns NNBVH_ERR_ARG for unknown keys. */
 int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value);
 
 /* diagnostics: wavefront scheduling statistics accumulated since the last reset —

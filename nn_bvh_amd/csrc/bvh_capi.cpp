@@ -78,6 +78,7 @@ struct nnbvh_scene {
     int has_host_prims = 0;
     int has_patches = 1;    // 0: no bilinear patches, the lean kernels (no ray direction parked in LDS) run
     int has_alpha = 0;      // alpha-tested triangles present: the ALPHA kernels run
+    int fused_batches = 1;  // nnbvh_trace_batches_device: one mode-3 launch where the batches allow it
     int int_repeat = 3;
     int max_grid_threads = 0;
     double build_ms[1] = {0};  // device build time of nnbvh_scene_create_gpu_build
@@ -644,6 +645,8 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
             return NNBVH_ERR_ARG;
         }
         s->int_repeat = value;
+    } else if (k == "fused_batches") {
+        s->fused_batches = value ? 1 : 0;
     } else if (k == "xcd_queues") {
         s->xcd_queues = value ? 1 : 0;
     } else if (k == "prim_weight") {
@@ -674,7 +677,7 @@ static Workspace *workspace_for(nnbvh_scene *s, hipStream_t stream) {
     if (it != s->workspaces.end()) return &it->second;
     Workspace w;
     const size_t spill_bytes = (size_t)(s->depth + 1) * (size_t)s->max_grid_threads * sizeof(uint2);
-    if (!hip_ok(hipMalloc((void **)&w.queue, kMaxQueues * kQueueStrideWords * sizeof(unsigned)),
+    if (!hip_ok(hipMalloc((void **)&w.queue, kMaxFusedBatches * kMaxQueues * kQueueStrideWords * sizeof(unsigned)),
                 "hipMalloc(queue)"))
         return nullptr;
     if (!hip_ok(hipMalloc((void **)&w.spill, spill_bytes), "hipMalloc(spill)")) {
@@ -791,6 +794,52 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
     if (!guard.ok) return NNBVH_ERR_DEVICE;
     std::lock_guard<std::mutex> lock(s->mu);
     hipStream_t stream = (hipStream_t)stream_;
+    // One launch for all batches (mode 3) when they are closest-hit / occlusion-only any-hit batches of
+    // fewer than 2^28 rays each: they share one ramp-up and one drain instead of paying one each.
+    bool fusable = s->fused_batches && n_batches <= kMaxFusedBatches && s->window == 8 && !s->has_alpha;
+    for (int i = 0; fusable && i < n_batches; ++i)
+        fusable = batches[i].n < (1LL << kFusedIndexBits) &&
+                  !(batches[i].kind == NNBVH_BATCH_ANY && (batches[i].d_nodes_visited || batches[i].d_prim_tests));
+    if (fusable) {
+        Workspace *w = workspace_for(s, stream);
+        if (!w) return NNBVH_ERR_DEVICE;
+        TraceParams p{};
+        p.wide = s->d_wide;
+        p.prims = s->d_prims;
+        std::memcpy(p.rootMin, s->bounds, 12);
+        std::memcpy(p.rootMax, s->bounds + 3, 12);
+        p.rootRef = s->root_ref;
+        p.queue = w->queue;
+        p.nQueues = s->xcd_queues ? kMaxQueues : 1;
+        p.primWeight = s->prim_weight;
+        p.refillWeight = s->refill_weight;
+        p.stats = s->d_stats;
+        p.intRepeat = s->int_repeat;
+        p.hasHostPrims = s->has_host_prims;
+        p.spill = w->spill;
+        int64_t total = 0;
+        for (int i = 0; i < n_batches; ++i) {
+            if (batches[i].n == 0) continue;  // empty batches take no slot
+            const int b = p.nBatches++;
+            p.bRays[b] = (const nnbvh_ray *)batches[i].d_rays;
+            p.bOut[b] = batches[i].d_out;
+            p.bN[b] = (long)batches[i].n;
+            if (batches[i].kind == NNBVH_BATCH_ANY) p.anyMask |= 1u << b;
+            total += batches[i].n;
+        }
+        if (p.nBatches == 0) return NNBVH_OK;
+        p.n = (long)total;
+        if (!hip_ok(launch_zero_queue(w->queue, kMaxFusedBatches * kMaxQueues * kQueueStrideWords, stream),
+                    "queue reset launch"))
+            return NNBVH_ERR_DEVICE;
+        int blocks = grid_blocks(s, 3);
+        const int64_t need = (total + kBlockThreads - 1) / kBlockThreads;
+        if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
+        if (!hip_ok(launch_trace(3, p, s->window, s->instanced, s->has_patches + 2 * s->has_alpha, blocks, stream,
+                                 nullptr), "fused trace kernel launch"))
+            return NNBVH_ERR_DEVICE;
+        return NNBVH_OK;
+    }
     if (!s->ev_fork) {
         bool ok = hip_ok(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming), "hipEventCreate");
         for (int k = 0; ok && k < nnbvh_scene::kSideStreams; ++k)

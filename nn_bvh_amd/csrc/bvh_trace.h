@@ -11,6 +11,8 @@ namespace nnbvh {
 constexpr int kBlockThreads = 256;   // 4 wavefronts
 constexpr int kMaxQueues = 8;        // one ray queue per XCD
 constexpr int kQueueStrideWords = 32;  // each queue head on its own 128-B line
+constexpr int kMaxFusedBatches = 4;    // batches one mode-3 launch may cover
+constexpr int kFusedIndexBits = 28;    // a lane's ray tag = batch << 28 | index: batches below 2^28 rays
 
 struct TraceParams {
     const float4 *wide;   // interior records, 4 x float4 each
@@ -32,6 +34,14 @@ struct TraceParams {
     int intRepeat;          // interior steps per scheduling decision (>= 1)
     unsigned long long *stats;  // NNBVH_STATS builds: trips/lanes per step kind; else unused
     uint2 *spill;           // [kMaxStack][grid threads] overflow of the LDS stack window
+    // mode 3 (one launch over several batches, closest-hit and occlusion-only any-hit mixed): batch
+    // b's rays / results / size, queue heads at queue[(b * nQueues + q) * kQueueStrideWords]; bit b
+    // of anyMask = batch b is any-hit (bOut = uint8 occluded[]), else closest (bOut = nnbvh_hit[])
+    int nBatches;
+    unsigned anyMask;
+    const nnbvh_ray *bRays[kMaxFusedBatches];
+    void *bOut[kMaxFusedBatches];
+    long bN[kMaxFusedBatches];
 };
 
 hipError_t launch_zero_queue(unsigned *queue, int words, hipStream_t stream);

@@ -38,6 +38,10 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 // MODE 0: closest hit (counts always)
 // MODE 1: any hit with exact node-visit / prim-test counts (pushes every far child)
 // MODE 2: any hit, occlusion flag only
+// MODE 3: several batches in ONE launch, each closest hit (as MODE 0) or occlusion-only any hit (as
+//         MODE 2): the batches of one wavefront iteration share a single ramp-up and a single drain
+//         (DESIGN.md §5g).  A lane's ray tag carries its batch; what differs per lane is only what a
+//         hit does and what is written at retire.
 //
 // Every lane is a small state machine over `cur`:
 //     cur >= 0            an interior record to process        (interior step)
@@ -71,7 +75,7 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 // ALPHA = 1: the scene holds alpha-tested triangles (kPrimAlpha, cpu/primitive.cpp:57-70); compiled
 // separately so that other scenes pay nothing for the hash and the re-trace.
 template <int MODE, int W, int INST, int PATCH, int ALPHA = 0>
-__global__ __launch_bounds__(kBlockThreads, (INST ? 1 : (MODE == 0 ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY) + (PATCH ? 0 : NNBVH_LEAN_EXTRA_WAVES)))
+__global__ __launch_bounds__(kBlockThreads, (INST ? 1 : ((MODE == 0 || MODE == 3) ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY) + (PATCH ? 0 : NNBVH_LEAN_EXTRA_WAVES)))
 void trace_kernel(TraceParams p) {
     static_assert(PATCH || !INST, "two-level scenes need the ray direction");
     static_assert(PATCH || !ALPHA, "the alpha test hashes the ray direction");
@@ -81,7 +85,7 @@ void trace_kernel(TraceParams p) {
     // ray index (read when the ray retires), the direction (read by the patch test only; the
     // triangle test uses the precomputed shear) and, closest hit, the current best hit
     // (written on an accepted hit, read at retire).  Frees 4 / 8 registers per lane.
-    constexpr int kColdRi = 0, kColdD = 1, kColdHit = PATCH ? 4 : 1, kColdHost = kColdHit + ((MODE == 0) ? 4 : 0);
+    constexpr int kColdRi = 0, kColdD = 1, kColdHit = PATCH ? 4 : 1, kColdHost = kColdHit + ((MODE == 0 || MODE == 3) ? 4 : 0);
     constexpr int kColdBase = kColdHost + 1;  // kColdHost: the ray reached a host-only primitive
     // two-level scenes: the outer ray saved while a child tree is traversed
     constexpr int kSaveO = kColdBase, kSaveInv = kColdBase + 3, kSaveShear = kColdBase + 6,
@@ -108,6 +112,7 @@ void trace_kernel(TraceParams p) {
         q = (int)(xcc & 0xf) % p.nQueues;
     }
     int queuesTried = 0;
+    int curBatch = 0;  // MODE 3: the batch this wave is drawing rays from (wave-uniform)
     // batch size: the host's bound, or a device-resident queue size below it (wavefront callers)
     long nRays = p.n;
     if (p.nDev) {
@@ -248,7 +253,29 @@ void trace_kernel(TraceParams p) {
         if (nIdle == 64 || (sR > sI && sR > sP)) {
             // ---- retire finished rays, refill idle lanes -------------------------------
             const int ri = isIdle ? __float_as_int(cold[kColdRi][lane]) : -1;
-            if (ri >= 0) {
+            if (MODE == 3 && ri >= 0) {
+                const int b = ri >> kFusedIndexBits;
+                const long idx = ri & ((1 << kFusedIndexBits) - 1);
+                void *outp = b == 0 ? p.bOut[0] : (b == 1 ? p.bOut[1] : (b == 2 ? p.bOut[2] : p.bOut[3]));
+                const bool needHost = p.hasHostPrims && cold[kColdHost][lane] != 0.0f;
+                if ((p.anyMask >> b) & 1u) {
+                    reinterpret_cast<uint8_t *>(outp)[idx] = found ? 1 : (needHost ? 2 : 0);
+                } else {
+                    float4 h0, h1;
+                    h0.x = cold[kColdHit][lane];
+                    h0.y = tMax;
+                    h0.z = cold[kColdHit + 1][lane];
+                    h0.w = cold[kColdHit + 2][lane];
+                    h1.x = cold[kColdHit + 3][lane];
+                    h1.y = __int_as_float(visited);
+                    h1.z = __int_as_float(tests);
+                    h1.w = INST ? cold[kHitInst][lane] : 0.0f;
+                    if (needHost) h1.w = __int_as_float(-1);
+                    float4 *out = reinterpret_cast<float4 *>(outp) + 2 * idx;
+                    out[0] = h0;
+                    out[1] = h1;
+                }
+            } else if (ri >= 0) {
                 if (MODE == 0) {
                     float4 h0, h1;
                     h0.x = cold[kColdHit][lane];  // hit primitive id (bit pattern)
@@ -276,9 +303,12 @@ void trace_kernel(TraceParams p) {
             if (exhausted) break;  // only reached with every lane idle (sR == 0 otherwise)
             long start = 0;
             for (;;) {  // find a queue with work left (own XCD's first, then steal)
+                if (MODE == 3) nRays = p.bN[curBatch];
                 const long qBegin = nRays * q / p.nQueues, qEnd = nRays * (q + 1) / p.nQueues;
                 unsigned got = 0;
-                if (lane == 0) got = atomicAdd(&p.queue[q * kQueueStrideWords], (unsigned)nIdle);
+                if (lane == 0)
+                    got = atomicAdd(&p.queue[((MODE == 3 ? curBatch * p.nQueues : 0) + q) * kQueueStrideWords],
+                                    (unsigned)nIdle);
                 got = __builtin_amdgcn_readfirstlane(got);
                 start = qBegin + (long)got;
                 if (start < qEnd) {
@@ -289,14 +319,22 @@ void trace_kernel(TraceParams p) {
                     break;
                 }
                 if (++queuesTried >= p.nQueues) {
+                    if (MODE == 3 && curBatch + 1 < p.nBatches) {  // this batch is handed out: on to the next
+                        ++curBatch;
+                        queuesTried = 0;
+                        continue;
+                    }
                     exhausted = true;
                     break;
                 }
                 q = (q + 1 == p.nQueues) ? 0 : q + 1;
             }
-            if (isIdle) cold[kColdRi][lane] = __int_as_float(newRi);
+            if (isIdle)
+                cold[kColdRi][lane] =
+                    __int_as_float((MODE == 3 && newRi >= 0) ? (newRi | (curBatch << kFusedIndexBits)) : newRi);
             if (newRi >= 0) {
-                const float4 *in = reinterpret_cast<const float4 *>(p.rays) + 2 * (long)newRi;
+                const nnbvh_ray *batchRays = MODE == 3 ? p.bRays[curBatch] : p.rays;
+                const float4 *in = reinterpret_cast<const float4 *>(batchRays) + 2 * (long)newRi;
                 const float4 r0 = in[0], r1 = in[1];
                 r.o = {r0.x, r0.y, r0.z};
                 tMax = r0.w;
@@ -309,7 +347,7 @@ void trace_kernel(TraceParams p) {
                 // aggregates.cpp:534-535
                 r.inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
                 ray_shear(r, d);
-                if (MODE == 0) {
+                if (MODE == 0 || MODE == 3) {
                     cold[kColdHit][lane] = __int_as_float(-1);
                     cold[kColdHit + 1][lane] = 0.0f;
                     cold[kColdHit + 2][lane] = 0.0f;
@@ -395,8 +433,11 @@ void trace_kernel(TraceParams p) {
                                              {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
                             next = slot + 4;
                         }
+                        bool closestLane = MODE == 0;
+                        if (MODE == 3 && hit)
+                            closestLane = !((p.anyMask >> (__float_as_int(cold[kColdRi][lane]) >> kFusedIndexBits)) & 1u);
                         if (hit) {
-                            if (MODE == 0) {
+                            if (closestLane) {
                                 cold[kColdHit][lane] = s0.w;  // primitive id bits
                                 cold[kColdHit + 1][lane] = x0;
                                 cold[kColdHit + 2][lane] = x1;
@@ -452,7 +493,7 @@ void trace_kernel(TraceParams p) {
                     sref[sp & (W - 1)][lane] = farRef;
                     skey[sp & (W - 1)][lane] = farE ? farT : __builtin_inff();
                     ++sp;
-                } else if (MODE == 0) {
+                } else if (MODE == 0 || MODE == 3) {
                     visited += 1;  // the reference pops and rejects it later: same count
                 }
                 if (nearE && nearT < tMax) cur = nearRef;
@@ -476,6 +517,15 @@ static hipError_t launch_one(const TraceParams &p, int blocks, hipStream_t strea
     hipLaunchKernelGGL((trace_kernel<MODE, W, INST, PATCH, ALPHA>), dim3((unsigned)blocks), dim3(kBlockThreads), 0,
                        stream, p);
     return hipGetLastError();
+}
+
+// mode 3 exists for the window-8 instances without alpha-tested triangles
+static hipError_t launch_fused(const TraceParams &p, int window, int instanced, int patches, int blocks,
+                               hipStream_t stream, int *occupancy) {
+    if (window != 8 || (patches & 2)) return hipErrorInvalidValue;
+    if (instanced) return launch_one<3, 8, 1, 1>(p, blocks, stream, occupancy);
+    if (!patches) return launch_one<3, 8, 0, 0>(p, blocks, stream, occupancy);
+    return launch_one<3, 8, 0, 1>(p, blocks, stream, occupancy);
 }
 
 template <int MODE>
@@ -511,6 +561,7 @@ hipError_t launch_trace(int mode, const TraceParams &p, int window, int instance
     case 0: return launch_mode<0>(p, window, instanced, patches, blocks, stream, occupancy);
     case 1: return launch_mode<1>(p, window, instanced, patches, blocks, stream, occupancy);
     case 2: return launch_mode<2>(p, window, instanced, patches, blocks, stream, occupancy);
+    case 3: return launch_fused(p, window, instanced, patches, blocks, stream, occupancy);
     default: return hipErrorInvalidValue;
     }
 }

@@ -243,6 +243,77 @@ def test_trace_batches_equals_separate_calls():
     agg.close()
 
 
+def test_fused_batches_one_launch_equals_the_oracle():
+    """nnbvh_trace_batches_device with closest / occlusion-only batches runs as ONE launch (mode 3:
+    the wavefronts drain the batches one after the other, lanes of one wave may carry rays of
+    different batches at the seams): results must be those of the separate entry points = the oracle,
+    for ragged batch sizes, host-only primitives, a scene with patches and a two-level scene."""
+    import torch
+    from nn_bvh_amd import HIT_DTYPE, instancing
+    from test_instancing import two_level_scene
+    st = torch.cuda.current_stream().cuda_stream
+
+    def dev(a):
+        return torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda()
+
+    def run(agg, batches):
+        outs, args = [], []
+        for kind, rays in batches:
+            d = dev(rays)
+            o = torch.full((max(len(rays), 1) * (32 if kind == "closest" else 1),), 0x5A, dtype=torch.uint8, device="cuda")
+            outs.append((kind, d, o))
+            args.append((kind, d.data_ptr(), len(rays), o.data_ptr()))
+        agg.trace_batches_device(args, st)
+        torch.cuda.synchronize()
+        return [o.cpu().numpy().view(HIT_DTYPE) if k == "closest" else o.cpu().numpy() for k, _, o in outs]
+
+    # lean scene (no patches): sizes that are no multiple of anything, one tiny, one of a single ray
+    verts, prims = ss.random_soup(4000, 0, 41)
+    tree = build_tree(prims, verts)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+    lo, hi = verts.min(0) - 1, verts.max(0) + 1
+    batches = [("closest", scene.random_rays(30011, lo, hi, 1)), ("any", scene.random_rays(7, lo, hi, 2, tmax=0.9)),
+               ("closest", scene.random_rays(1, lo, hi, 3)), ("any", scene.random_rays(20333, lo, hi, 4, tmax=0.7))]
+    got = run(agg, batches)
+    for (kind, rays), g in zip(batches, got):
+        if kind == "closest":
+            assert g.tobytes() == ob.closest(tree.nodes, tree.ordered_prims, verts, rays, 4).tobytes()
+        else:
+            assert np.array_equal(g[:len(rays)], ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, 4)[0])
+    # the multi-stream path gives the same
+    agg.set_option("fused_batches", 0)
+    again = run(agg, batches)
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(got, again))
+    agg.close()
+    # patches + host-only primitives (general kernels)
+    verts, prims = ss.random_soup(3000, 400, 42)
+    extra = np.zeros(20, prims.dtype)
+    extra["kind"], extra["id"] = 3, len(prims) + np.arange(20)
+    allp = np.concatenate([prims, extra])
+    rng = np.random.default_rng(5)
+    blo = rng.uniform(-8, 8, (len(allp), 3)).astype(np.float32)
+    pb = np.concatenate([blo, blo + rng.uniform(0.5, 2, (len(allp), 3)).astype(np.float32)], 1)
+    tree = build_tree(allp, verts, prim_bounds=pb)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+    batches = [("any", scene.random_rays(9001, verts.min(0) - 2, verts.max(0) + 2, 6)),
+               ("closest", scene.random_rays(15013, verts.min(0) - 2, verts.max(0) + 2, 7))]
+    got = run(agg, batches)
+    assert np.array_equal(got[0], ob.any_hit(tree.nodes, tree.ordered_prims, verts, batches[0][1], 4)[0])
+    exp = ob.closest(tree.nodes, tree.ordered_prims, verts, batches[1][1], 4)
+    assert got[1].tobytes() == exp.tobytes() and (exp["instance"] == -1).any() and (got[0] == 2).any()
+    agg.close()
+    # two-level scene
+    verts, nodes, aprims, instances, n_top, _ = two_level_scene(5, 20)
+    agg = BVHAggregate.from_tree(nodes, aprims, verts, instances=instances, n_top_nodes=n_top)
+    ra = scene.random_rays(12007, [-30, -30, -30], [30, 30, 30], 8)
+    rb = scene.random_rays(8003, [-30, -30, -30], [30, 30, 30], 9, tmax=0.8)
+    got = run(agg, [("closest", ra), ("any", rb)])
+    assert got[0].tobytes() == ob.closest_inst(nodes, aprims, verts, instances, ra, 4).tobytes()
+    assert np.array_equal(got[1], ob.any_hit_inst(nodes, aprims, verts, instances, rb, 4)[0])
+    agg.close()
+    del instancing
+
+
 def test_concurrent_host_threads_and_streams():
     """The ABI's thread-safety contract: concurrent calls from several host threads on one
     scene, and concurrent device-pointer launches on several streams, give each call exactly
