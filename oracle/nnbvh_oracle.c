@@ -440,6 +440,175 @@ void orc_transform_bounds(const float m[12], const float in[6], float out[6]) {
     memcpy(out + 3, mx, 12);
 }
 
+/* ---- AnimatedTransform::Interpolate, util/transform.cpp:1062-1081 ------------------------------ */
+static void mat4_mul(const float a[16], const float b[16], float r[16]) { /* math.h:1499-1509 */
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0;
+            for (int k = 0; k < 4; ++k) acc = fmaf(a[4 * i + k], b[4 * k + j], acc);
+            r[4 * i + j] = acc;
+        }
+}
+
+/* internal::InnerProduct / TwoProd / TwoSum, util/math.h:585-612 and float.h compensated arithmetic */
+typedef struct {
+    float v, err;
+} orc_cf;
+static orc_cf two_prod(float a, float b) {
+    float ab = a * b;
+    orc_cf r = {ab, fmaf(a, b, -ab)};
+    return r;
+}
+static orc_cf two_sum(float a, float b) {
+    float s = a + b, delta = s - a;
+    orc_cf r = {s, (a - (s - delta)) + (b - delta)};
+    return r;
+}
+static orc_cf inner_rec(const float *t, int n) { /* n pairs */
+    orc_cf ab = two_prod(t[0], t[1]);
+    if (n == 1) return ab;
+    orc_cf tp = inner_rec(t + 2, n - 1);
+    orc_cf sum = two_sum(ab.v, tp.v);
+    orc_cf r = {sum.v, ab.err + (tp.err + sum.err)};
+    return r;
+}
+static float inner3(float a0, float b0, float a1, float b1, float a2, float b2) {
+    const float t[6] = {a0, b0, a1, b1, a2, b2};
+    orc_cf ip = inner_rec(t, 3);
+    return ip.v + ip.err;
+}
+static float inner6(const float t[12]) {
+    orc_cf ip = inner_rec(t, 6);
+    return ip.v + ip.err;
+}
+
+/* Inverse(const SquareMatrix<4> &), util/math.h:1572-1625; returns 0 for a singular matrix */
+static int mat4_inverse(const float mm[16], float out[16]) {
+#define M(i, j) mm[4 * (i) + (j)]
+    float s0 = orc_dop(M(0, 0), M(1, 1), M(1, 0), M(0, 1));
+    float s1 = orc_dop(M(0, 0), M(1, 2), M(1, 0), M(0, 2));
+    float s2 = orc_dop(M(0, 0), M(1, 3), M(1, 0), M(0, 3));
+    float s3 = orc_dop(M(0, 1), M(1, 2), M(1, 1), M(0, 2));
+    float s4 = orc_dop(M(0, 1), M(1, 3), M(1, 1), M(0, 3));
+    float s5 = orc_dop(M(0, 2), M(1, 3), M(1, 2), M(0, 3));
+    float c0 = orc_dop(M(2, 0), M(3, 1), M(3, 0), M(2, 1));
+    float c1 = orc_dop(M(2, 0), M(3, 2), M(3, 0), M(2, 2));
+    float c2 = orc_dop(M(2, 0), M(3, 3), M(3, 0), M(2, 3));
+    float c3 = orc_dop(M(2, 1), M(3, 2), M(3, 1), M(2, 2));
+    float c4 = orc_dop(M(2, 1), M(3, 3), M(3, 1), M(2, 3));
+    float c5 = orc_dop(M(2, 2), M(3, 3), M(3, 2), M(2, 3));
+    const float dt[12] = {s0, c5, -s1, c4, s2, c3, s3, c2, s5, c0, -s4, c1};
+    float determinant = inner6(dt);
+    if (determinant == 0) return 0;
+    float s = 1 / determinant;
+    out[0] = s * inner3(M(1, 1), c5, M(1, 3), c3, -M(1, 2), c4);
+    out[1] = s * inner3(-M(0, 1), c5, M(0, 2), c4, -M(0, 3), c3);
+    out[2] = s * inner3(M(3, 1), s5, M(3, 3), s3, -M(3, 2), s4);
+    out[3] = s * inner3(-M(2, 1), s5, M(2, 2), s4, -M(2, 3), s3);
+    out[4] = s * inner3(-M(1, 0), c5, M(1, 2), c2, -M(1, 3), c1);
+    out[5] = s * inner3(M(0, 0), c5, M(0, 3), c1, -M(0, 2), c2);
+    out[6] = s * inner3(-M(3, 0), s5, M(3, 2), s2, -M(3, 3), s1);
+    out[7] = s * inner3(M(2, 0), s5, M(2, 3), s1, -M(2, 2), s2);
+    out[8] = s * inner3(M(1, 0), c4, M(1, 3), c0, -M(1, 1), c2);
+    out[9] = s * inner3(-M(0, 0), c4, M(0, 1), c2, -M(0, 3), c0);
+    out[10] = s * inner3(M(3, 0), s4, M(3, 3), s0, -M(3, 1), s2);
+    out[11] = s * inner3(-M(2, 0), s4, M(2, 1), s2, -M(2, 3), s0);
+    out[12] = s * inner3(-M(1, 0), c3, M(1, 1), c1, -M(1, 2), c0);
+    out[13] = s * inner3(M(0, 0), c3, M(0, 2), c0, -M(0, 1), c1);
+    out[14] = s * inner3(-M(3, 0), s3, M(3, 1), s1, -M(3, 2), s0);
+    out[15] = s * inner3(M(2, 0), s3, M(2, 2), s0, -M(2, 1), s1);
+#undef M
+    return 1;
+}
+
+static float sin_x_over_x(float x) { /* util/math.h:340-344 */
+    if (1 - x * x == 1) return 1;
+    return sinf(x) / x;
+}
+static float quat_dot(const float a[4], const float b[4]) { /* vecmath.h:1126-1128, 964-967 */
+    return (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) + a[3] * b[3];
+}
+static float quat_angle_between(const float q1[4], const float q2[4]) { /* vecmath.h:1138-1143 */
+    float t[4];
+    if (quat_dot(q1, q2) < 0) {
+        for (int k = 0; k < 4; ++k) t[k] = q1[k] + q2[k];
+        float x = sqrtf(quat_dot(t, t)) / 2;
+        x = x < -1 ? -1 : (x > 1 ? 1 : x); /* SafeASin: Clamp(x, -1, 1) */
+        return 3.14159265358979323846f - 2 * asinf(x);
+    }
+    for (int k = 0; k < 4; ++k) t[k] = q2[k] - q1[k];
+    float x = sqrtf(quat_dot(t, t)) / 2;
+    x = x < -1 ? -1 : (x > 1 ? 1 : x);
+    return 2 * asinf(x);
+}
+
+void orc_anim_interpolate(const orc_anim *a, float time, float m[16], float minv[16]) {
+    if (!a->actually_animated || time <= a->start_time) { /* :1064-1065 */
+        memcpy(m, a->start_m, 64);
+        memcpy(minv, a->start_minv, 64);
+        return;
+    }
+    if (time >= a->end_time) { /* :1066-1067 */
+        memcpy(m, a->end_m, 64);
+        memcpy(minv, a->end_minv, 64);
+        return;
+    }
+    const float dt = (time - a->start_time) / (a->end_time - a->start_time);
+    float trans[3];
+    for (int k = 0; k < 3; ++k) trans[k] = (1 - dt) * a->T[0][k] + dt * a->T[1][k];
+    /* Slerp(dt, R[0], R[1]), vecmath.h:1146-1151 */
+    const float theta = quat_angle_between(a->R[0], a->R[1]);
+    const float sinThetaOverTheta = sin_x_over_x(theta);
+    const float w1 = sin_x_over_x((1 - dt) * theta), w2 = sin_x_over_x(dt * theta);
+    float q[4];
+    for (int k = 0; k < 4; ++k)
+        q[k] = a->R[0][k] * (1 - dt) * w1 / sinThetaOverTheta + a->R[1][k] * dt * w2 / sinThetaOverTheta;
+    float scale[16];
+    for (int k = 0; k < 16; ++k) scale[k] = a->S[0][k] * (1 - dt) + a->S[1][k] * dt; /* (1-dt)*S0 + dt*S1 = S*s */
+    /* Translate(trans), transform.cpp:21-31 */
+    float tm[16] = {1, 0, 0, trans[0], 0, 1, 0, trans[1], 0, 0, 1, trans[2], 0, 0, 0, 1};
+    float tmi[16] = {1, 0, 0, -trans[0], 0, 1, 0, -trans[1], 0, 0, 1, -trans[2], 0, 0, 0, 1};
+    /* Transform(Quaternion q), transform.h:367-385: mInv from q, m = Transpose(mInv) */
+    const float xx = q[0] * q[0], yy = q[1] * q[1], zz = q[2] * q[2];
+    const float xy = q[0] * q[1], xz = q[0] * q[2], yz = q[1] * q[2];
+    const float wx = q[0] * q[3], wy = q[1] * q[3], wz = q[2] * q[3];
+    float rmi[16] = {1 - 2 * (yy + zz), 2 * (xy + wz), 2 * (xz - wy), 0,
+                     2 * (xy - wz), 1 - 2 * (xx + zz), 2 * (yz + wx), 0,
+                     2 * (xz + wy), 2 * (yz - wx), 1 - 2 * (xx + yy), 0,
+                     0, 0, 0, 1};
+    float rm[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) rm[4 * i + j] = rmi[4 * j + i];
+    /* Transform(scale): mInv = Inverse(scale), NaN-filled when singular (transform.h:64-75) */
+    float smi[16];
+    if (!mat4_inverse(scale, smi))
+        for (int k = 0; k < 16; ++k) smi[k] = NAN;
+    /* Translate * Rotate * Scale: (A * B).m = A.m * B.m, .mInv = B.mInv * A.mInv (transform.cpp:141-143) */
+    float tr[16], tri[16];
+    mat4_mul(tm, rm, tr);
+    mat4_mul(rmi, tmi, tri);
+    mat4_mul(tr, scale, m);
+    mat4_mul(smi, tri, minv);
+}
+
+void orc_anim_interpolate_batch(const orc_anim *a, const float *time, int n, float *out32) {
+    for (int i = 0; i < n; ++i) orc_anim_interpolate(&a[i], time[i], out32 + 32 * i, out32 + 32 * i + 16);
+}
+
+/* the animation table and the current ray's time for the two-level traversal below (per worker thread) */
+static __thread const orc_anim *g_anims = NULL;
+static __thread float g_ray_time = 0.0f;
+/* the 3x4 inverse matrix AnimatedPrimitive / TransformedPrimitive apply to the ray */
+static void instance_minv(const orc_instance *in, int index, float out12[12]) {
+    if (g_anims && g_anims[index].actually_animated) {
+        float m[16], mi[16];
+        orc_anim_interpolate(&g_anims[index], g_ray_time, m, mi);
+        memcpy(out12, mi, 48);
+    } else {
+        memcpy(out12, in->m_inv, 48);
+    }
+}
+
 /* ---- primitive dispatch (cpu/primitive.cpp:24-32 -> shapes.cpp:320-358, 1131-1156) --- */
 static inline int prim_test(const orc_prim *p, const float *verts, const float o[3],
                             const float d[3], float tmax, float res[4]) {
@@ -525,8 +694,9 @@ static void closest_tree(const orc_node *nodes, const orc_prim *prims, const flo
                     }
                     if (p->kind == 2) { /* TransformedPrimitive::Intersect */
                         const orc_instance *in = &instances[p->v[0]];
-                        float x[7];
-                        orc_apply_inverse_ray(in->m_inv, o, d, tmax, x);
+                        float x[7], mi12[12];
+                        instance_minv(in, p->v[0], mi12); /* AnimatedPrimitive: Interpolate(r.time), primitive.cpp:143 */
+                        orc_apply_inverse_ray(mi12, o, d, tmax, x);
                         float inner_tmax = x[6];
                         orc_hit inner = *hit;
                         inner.prim = -1;
@@ -615,8 +785,9 @@ static int any_tree(const orc_node *nodes, const orc_prim *prims, const float *v
                     }
                     if (p->kind == 2) { /* TransformedPrimitive::IntersectP, primitive.cpp:128-131 */
                         const orc_instance *in = &instances[p->v[0]];
-                        float x[7];
-                        orc_apply_inverse_ray(in->m_inv, o, d, tmax, x);
+                        float x[7], mi12[12];
+                        instance_minv(in, p->v[0], mi12);
+                        orc_apply_inverse_ray(mi12, o, d, tmax, x);
                         if (any_tree(nodes, prims, verts, instances, in->root, x, x + 3, x[6],
                                      &visited, &tests, host_io)) {
                             found = 1;
@@ -675,6 +846,7 @@ typedef struct {
     const orc_prim *prims;
     const float *verts;
     const orc_instance *instances;
+    const orc_anim *anims;
     const orc_ray *rays;
     int64_t begin, end;
     orc_hit *hits;
@@ -686,7 +858,9 @@ typedef struct {
 
 static void *orc_worker(void *arg) {
     orc_job *j = (orc_job *)arg;
+    g_anims = j->anims;
     for (int64_t i = j->begin; i < j->end; ++i) {
+        g_ray_time = j->rays[i].time;
         if (j->any) {
             int v, t;
             int f = any_one(j->nodes, j->prims, j->verts, j->instances, &j->rays[i], &v, &t);
@@ -776,6 +950,40 @@ void orc_intersect_any_inst(const orc_node *nodes, const orc_prim *prims, const 
     j.prims = prims;
     j.verts = verts;
     j.instances = instances;
+    j.rays = rays;
+    j.occ = occluded;
+    j.visited = nodes_visited;
+    j.tests = prim_tests;
+    j.any = 1;
+    orc_run(j, n, nthreads);
+}
+
+void orc_intersect_closest_anim(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                                const orc_instance *instances, const orc_anim *anims, const orc_ray *rays,
+                                int64_t n, orc_hit *hits, int nthreads) {
+    orc_job j;
+    memset(&j, 0, sizeof j);
+    j.nodes = nodes;
+    j.prims = prims;
+    j.verts = verts;
+    j.instances = instances;
+    j.anims = anims;
+    j.rays = rays;
+    j.hits = hits;
+    orc_run(j, n, nthreads);
+}
+
+void orc_intersect_any_anim(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                            const orc_instance *instances, const orc_anim *anims, const orc_ray *rays,
+                            int64_t n, uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests,
+                            int nthreads) {
+    orc_job j;
+    memset(&j, 0, sizeof j);
+    j.nodes = nodes;
+    j.prims = prims;
+    j.verts = verts;
+    j.instances = instances;
+    j.anims = anims;
     j.rays = rays;
     j.occ = occluded;
     j.visited = nodes_visited;

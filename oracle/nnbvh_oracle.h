@@ -152,6 +152,31 @@ void orc_hash_batch(const float *in6, int n, uint32_t *lo, uint32_t *hi, float *
 void orc_offset_batch(const float *in12, int n, float *out9);
 void orc_wrs_batch(const float *in7, int n, int32_t *selected, float *out2);
 
+/* AnimatedTransform's members (util/transform.h:443-520) as the reference object holds them after
+ * construction, and AnimatedTransform::Interpolate (util/transform.cpp:1062-1081): Translate(lerp T) *
+ * Transform(Slerp(R)) * Transform(lerp S) with Transform::operator* (FMA chains, math.h:1499-1509) and the
+ * 4x4 Inverse of math.h:1572-1625.  Matrices are full 4x4, row-major. */
+typedef struct {
+    float start_m[16], start_minv[16], end_m[16], end_minv[16];
+    float T[2][3];
+    float R[2][4]; /* v.x v.y v.z w */
+    float S[2][16];
+    float start_time, end_time;
+    int32_t actually_animated;
+    int32_t pad;
+} orc_anim;
+void orc_anim_interpolate(const orc_anim *a, float time, float m[16], float minv[16]);
+void orc_anim_interpolate_batch(const orc_anim *a, const float *time, int n, float *out32);
+/* two-level traversal with AnimatedPrimitive instances (cpu/primitive.cpp:133-158): anims[k] belongs to
+ * instances[k]; entries with actually_animated == 0 are TransformedPrimitives */
+void orc_intersect_closest_anim(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                                const orc_instance *instances, const orc_anim *anims, const orc_ray *rays,
+                                int64_t n, orc_hit *hits, int nthreads);
+void orc_intersect_any_anim(const orc_node *nodes, const orc_prim *prims, const float *verts,
+                            const orc_instance *instances, const orc_anim *anims, const orc_ray *rays,
+                            int64_t n, uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests,
+                            int nthreads);
+
 /* UpdateFilm + RGBFilm::AddSample (wavefront/film.cpp:13-40, film.h:239-255) without the spectral
  * sensor conversion: sample (pass, i) of pixel slot i adds weight * clamp(rgb) to pixels[4 * pixel]
  * (double rgbSum[3], weightSum; film.h:302-307), passes in order.  bounds = x0 y0 x1 y1. */

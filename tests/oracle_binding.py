@@ -275,3 +275,48 @@ def wrs_batch(in7):
     out = np.zeros((len(in7), 2), np.float32)
     lib().orc_wrs_batch(_p(in7), ctypes.c_int(len(in7)), _p(sel), _p(out))
     return sel, out
+
+
+def _inst(instances):
+    return np.ascontiguousarray(instances, INSTANCE_DTYPE)
+
+
+ANIM_DTYPE = np.dtype([("start_m", "<f4", 16), ("start_minv", "<f4", 16), ("end_m", "<f4", 16),
+                       ("end_minv", "<f4", 16), ("T", "<f4", (2, 3)), ("R", "<f4", (2, 4)), ("S", "<f4", (2, 16)),
+                       ("start_time", "<f4"), ("end_time", "<f4"), ("actually_animated", "<i4"), ("pad", "<i4")])
+
+
+def anim_interpolate(anims, times):
+    """AnimatedTransform::Interpolate per record: float32 [n, 32] = m (16), mInv (16)."""
+    a = np.ascontiguousarray(anims, ANIM_DTYPE)
+    t = np.ascontiguousarray(times, np.float32)
+    out = np.zeros((len(a), 32), np.float32)
+    lib().orc_anim_interpolate_batch(_p(a), _p(t), ctypes.c_int(len(a)), _p(out))
+    return out
+
+
+def closest_anim(nodes, prims, verts, instances, anims, rays, nthreads=1):
+    from nn_bvh_amd._lib import HIT_DTYPE
+    nodes, prims = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+    verts = np.ascontiguousarray(verts, np.float32)
+    inst = _inst(instances)
+    an = np.ascontiguousarray(anims, ANIM_DTYPE)
+    rays = np.ascontiguousarray(rays)
+    hits = np.zeros(len(rays), HIT_DTYPE)
+    lib().orc_intersect_closest_anim(_p(nodes), _p(prims), _p(verts), _p(inst), _p(an), _p(rays),
+                                     ctypes.c_int64(len(rays)), _p(hits), ctypes.c_int(nthreads))
+    return hits
+
+
+def any_hit_anim(nodes, prims, verts, instances, anims, rays, nthreads=1):
+    nodes, prims = np.ascontiguousarray(nodes), np.ascontiguousarray(prims)
+    verts = np.ascontiguousarray(verts, np.float32)
+    inst = _inst(instances)
+    an = np.ascontiguousarray(anims, ANIM_DTYPE)
+    rays = np.ascontiguousarray(rays)
+    occ = np.zeros(len(rays), np.uint8)
+    vis = np.zeros(len(rays), np.int32)
+    tst = np.zeros(len(rays), np.int32)
+    lib().orc_intersect_any_anim(_p(nodes), _p(prims), _p(verts), _p(inst), _p(an), _p(rays),
+                                 ctypes.c_int64(len(rays)), _p(occ), _p(vis), _p(tst), ctypes.c_int(nthreads))
+    return occ, vis, tst
