@@ -171,6 +171,33 @@ nnbvh_scene *nnbvh_scene_create_instanced(const nnbvh_linear_node *nodes, int n_
                                           int n_prims, const float *verts, int n_verts,
                                           const nnbvh_instance *instances, int n_instances,
                                           int device);
+/* AnimatedPrimitive (cpu/primitive.h:103-118; cpu/primitive.cpp:133-158): an instance whose
+ * render-from-instance transform is an AnimatedTransform.  The struct carries the members the
+ * reference object holds after construction (util/transform.h:443-520: start / end transform, the
+ * decomposition T, R, S of util/transform.cpp:375-394 and the time range); per ray the device evaluates
+ * AnimatedTransform::Interpolate(ray.time) (util/transform.cpp:1062-1081) and applies its inverse as
+ * for a static instance.  Arithmetic is the reference's operation for operation except the two sines of
+ * Slerp, which the device evaluates in fp64 and rounds (libm's sinf differs from the correctly rounded
+ * value on about one input in 10^5): the traversal path's one documented tolerance exception.
+ * Bounds of such a primitive (AnimatedTransform::MotionBounds) come from the caller via prim_bounds,
+ * like every instance's.  Hits inside animated instances get NNBVH_INTERACTION_HOST from the
+ * interaction post-pass. */
+typedef struct nnbvh_animated_transform {
+    float start_from[16], start_inv[16]; /* startTransform m / mInv, row-major 4x4 */
+    float end_from[16], end_inv[16];
+    float T[2][3];
+    float R[2][4];                       /* quaternion v.x v.y v.z w */
+    float S[2][16];
+    float start_time, end_time;
+    int32_t actually_animated;           /* 0: a TransformedPrimitive (the nnbvh_instance matrices are used) */
+    int32_t pad;
+} nnbvh_animated_transform;
+/* as nnbvh_scene_create_instanced; animated[k] (nullable array) belongs to instances[k] */
+nnbvh_scene *nnbvh_scene_create_instanced_animated(const nnbvh_linear_node *nodes, int n_nodes,
+                                                   int n_top_nodes, const nnbvh_prim *ordered_prims,
+                                                   int n_prims, const float *verts, int n_verts,
+                                                   const nnbvh_instance *instances, int n_instances,
+                                                   const nnbvh_animated_transform *animated, int device);
 /* Transform::operator()(const Bounds3f&) (util/transform.cpp:134-139): the bounds an instance
  * primitive presents to the top-level builder (TransformedPrimitive::Bounds, primitive.h:94) */
 void nnbvh_transform_bounds(const float render_from_prim[12], const float in_min_max[6],

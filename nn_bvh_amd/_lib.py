@@ -16,6 +16,9 @@ PRIM_DTYPE = np.dtype([("kind", "<i4"), ("id", "<i4"), ("v", "<i4", 4)])
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("tmax", "<f4"), ("d", "<f4", 3), ("time", "<f4")])
 INSTANCE_DTYPE = np.dtype([("render_from_prim", "<f4", 12), ("prim_from_render", "<f4", 12),
                            ("root", "<i4"), ("n_nodes", "<i4")])
+ANIMATED_DTYPE = np.dtype([("start_from", "<f4", 16), ("start_inv", "<f4", 16), ("end_from", "<f4", 16),
+                           ("end_inv", "<f4", 16), ("T", "<f4", (2, 3)), ("R", "<f4", (2, 4)), ("S", "<f4", (2, 16)),
+                           ("start_time", "<f4"), ("end_time", "<f4"), ("actually_animated", "<i4"), ("pad", "<i4")])
 BATCH_DTYPE = np.dtype([("kind", "<i4"), ("pad", "<i4"), ("d_rays", "<u8"), ("n", "<i8"),
                         ("d_out", "<u8"), ("d_nodes_visited", "<u8"), ("d_prim_tests", "<u8")])
 HIT_DTYPE = np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"),
@@ -58,6 +61,7 @@ EXPORTS = [
     "nnbvh_kd_scene_create", "nnbvh_kd_scene_destroy", "nnbvh_kd_intersect_closest", "nnbvh_kd_intersect_any",
     "nnbvh_kd_intersect_closest_device", "nnbvh_kd_intersect_any_device",
     "nnbvh_wavefront_intersect_shadow_tr", "nnbvh_wavefront_intersect_one_random",
+    "nnbvh_scene_create_instanced_animated",
 ]
 
 _lib = None
@@ -117,6 +121,8 @@ def lib():
     L.nnbvh_scene_set_option.argtypes = [vp, ctypes.c_char_p, i32]
     L.nnbvh_scene_create_instanced.restype = vp
     L.nnbvh_scene_create_instanced.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32]
+    L.nnbvh_scene_create_instanced_animated.restype = vp
+    L.nnbvh_scene_create_instanced_animated.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32]
     L.nnbvh_transform_bounds.restype = None
     L.nnbvh_transform_bounds.argtypes = [vp, vp, vp]
     L.nnbvh_build_create_with_bounds.restype = vp

@@ -116,11 +116,12 @@ class BVHAggregate:
         self._init(tree.nodes, tree.ordered_prims, verts, device, tree.depth)
 
     @classmethod
-    def from_tree(cls, nodes, ordered_prims, verts, device=0, instances=None, n_top_nodes=None):
+    def from_tree(cls, nodes, ordered_prims, verts, device=0, instances=None, n_top_nodes=None, animated=None):
         """instances (INSTANCE_DTYPE) + n_top_nodes make a two-level scene: nodes[:n_top_nodes] is
-        the top-level tree, the child trees follow (see nn_bvh_amd.instancing)."""
+        the top-level tree, the child trees follow (see nn_bvh_amd.instancing).  animated
+        (ANIMATED_DTYPE, one per instance) turns instances into AnimatedPrimitives."""
         self = cls.__new__(cls)
-        self._init(nodes, ordered_prims, verts, device, None, instances, n_top_nodes)
+        self._init(nodes, ordered_prims, verts, device, None, instances, n_top_nodes, animated)
         return self
 
     @classmethod
@@ -157,7 +158,7 @@ class BVHAggregate:
                      "depth": int(info[2]), "device_bytes": int(info[3]),
                      "grid_blocks": int(info[4]), "stack_window": int(info[5])}
 
-    def _init(self, nodes, ordered_prims, verts, device, depth, instances=None, n_top_nodes=None):
+    def _init(self, nodes, ordered_prims, verts, device, depth, instances=None, n_top_nodes=None, animated=None):
         L = _lib.lib()
         self.nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
         self.ordered_prims = np.ascontiguousarray(ordered_prims, PRIM_DTYPE)
@@ -165,10 +166,18 @@ class BVHAggregate:
         self.device = int(device)
         if instances is not None and len(instances):
             self.instances = np.ascontiguousarray(instances, _lib.INSTANCE_DTYPE)
-            self._h = L.nnbvh_scene_create_instanced(
-                ptr(self.nodes), len(self.nodes), int(n_top_nodes), ptr(self.ordered_prims),
-                len(self.ordered_prims), ptr(self.verts), len(self.verts), ptr(self.instances),
-                len(self.instances), self.device)
+            if animated is not None:
+                self.animated = np.ascontiguousarray(animated, _lib.ANIMATED_DTYPE)
+                assert len(self.animated) == len(self.instances)
+                self._h = L.nnbvh_scene_create_instanced_animated(
+                    ptr(self.nodes), len(self.nodes), int(n_top_nodes), ptr(self.ordered_prims),
+                    len(self.ordered_prims), ptr(self.verts), len(self.verts), ptr(self.instances),
+                    len(self.instances), ptr(self.animated), self.device)
+            else:
+                self._h = L.nnbvh_scene_create_instanced(
+                    ptr(self.nodes), len(self.nodes), int(n_top_nodes), ptr(self.ordered_prims),
+                    len(self.ordered_prims), ptr(self.verts), len(self.verts), ptr(self.instances),
+                    len(self.instances), self.device)
         else:
             self._h = L.nnbvh_scene_create(ptr(self.nodes), len(self.nodes), ptr(self.ordered_prims),
                                            len(self.ordered_prims), ptr(self.verts), len(self.verts),

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnnbvh_hip.so")
 SOURCES = ["bvh_trace.hip", "wavefront.hip", "wavefront2.hip", "bvh_build_gpu.hip", "bvh_bake.hip", "interaction.hip", "film.hip", "kd_trace.hip", "bvh_capi.cpp", "bvh_build.cpp", "kd_build.cpp"]
-HEADERS = ["bvh_trace.h", "trace_math.h", "spawn_math.h", "wavefront2.h", "wavefront.h", "bvh_build_gpu.h", "interaction.h", "nnbvh_internal.h", os.path.join("..", "..", "include", "nnbvh.h")]
+HEADERS = ["bvh_trace.h", "trace_math.h", "spawn_math.h", "anim_math.h", "wavefront2.h", "wavefront.h", "bvh_build_gpu.h", "interaction.h", "nnbvh_internal.h", os.path.join("..", "..", "include", "nnbvh.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 

@@ -66,6 +66,7 @@ struct nnbvh_scene {
     int root_ref = 0;
     float4 *d_wide = nullptr;
     float4 *d_prims = nullptr;
+    float *d_anim = nullptr;  // AnimatedPrimitive table (kAnimStride floats per instance), or null
     size_t device_bytes = 0;
     // tuning (speed only)
     int window = 8;
@@ -269,10 +270,28 @@ static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int
     return ok ? scene_from_baked(b, depth, device) : nullptr;
 }
 
+// AngleBetween(Quaternion, Quaternion) (util/vecmath.h:1138-1143) and SinXOverX (util/math.h:340-344) with
+// the host's libm, as the reference's Slerp evaluates them; they depend on the transform only
+static float quat_dot_host(const float a[4], const float b[4]) {
+    return (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) + a[3] * b[3];
+}
+static float quat_angle_between_host(const float q1[4], const float q2[4]) {
+    float t[4];
+    const bool neg = quat_dot_host(q1, q2) < 0;
+    for (int k = 0; k < 4; ++k) t[k] = neg ? q1[k] + q2[k] : q2[k] - q1[k];
+    float x = std::sqrt(quat_dot_host(t, t)) / 2;
+    x = x < -1 ? -1 : (x > 1 ? 1 : x);
+    return neg ? 3.14159265358979323846f - 2 * std::asin(x) : 2 * std::asin(x);
+}
+static float sin_x_over_x_host(float x) {
+    if (1 - x * x == 1) return 1;
+    return std::sin(x) / x;
+}
+
 static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, int n_top_nodes,
                                  const nnbvh_prim *prims, int n_prims, const float *verts,
                                  int n_verts, const nnbvh_instance *instances, int n_instances,
-                                 int device) {
+                                 int device, const nnbvh_animated_transform *animated = nullptr) {
     if (!nodes || !prims || !verts || n_prims <= 0 || n_verts <= 0 || n_instances < 0 ||
         (n_instances > 0 && !instances) || n_top_nodes < 1 || n_top_nodes > n_nodes) {
         set_error("scene_create: null or empty input array");
@@ -359,6 +378,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
             const nnbvh_instance &in = instances[p.v[0]];
             const nnbvh_linear_node &root = nodes[in.root];
             flags |= kPrimInstance;
+            if (animated && animated[p.v[0]].actually_animated) flags |= kPrimAnimated;
             put3(s, 0, root.pmin);
             put3(s, 4, root.pmax);
             std::memcpy(&s[3], &p.v[0], 4);  // instance index (reported +1 in nnbvh_hit.instance)
@@ -447,6 +467,28 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
         return nullptr;
     }
     s->device_bytes = wide_bytes + prim_bytes;
+    if (animated && n_instances > 0) {
+        std::vector<float> table((size_t)n_instances * kAnimStride, 0.0f);
+        for (int k = 0; k < n_instances; ++k) {
+            const nnbvh_animated_transform &a = animated[k];
+            float *t = &table[(size_t)k * kAnimStride];
+            std::memcpy(t, a.T, 24);
+            std::memcpy(t + 6, a.R, 32);
+            std::memcpy(t + 14, a.S, 128);
+            t[46] = a.start_time;
+            t[47] = a.end_time;
+            t[48] = quat_angle_between_host(a.R[0], a.R[1]);
+            t[49] = sin_x_over_x_host(t[48]);
+            std::memcpy(t + 50, a.start_inv, 48);
+            std::memcpy(t + 62, a.end_inv, 48);
+        }
+        if (!hip_ok(hipMalloc((void **)&s->d_anim, table.size() * 4), "hipMalloc(animation table)") ||
+            !hip_ok(hipMemcpy(s->d_anim, table.data(), table.size() * 4, hipMemcpyHostToDevice),
+                    "hipMemcpy(animation table)")) {
+            nnbvh_scene_destroy(s);
+            return nullptr;
+        }
+    }
     if (hipMalloc((void **)&s->d_stats, 16 * sizeof(unsigned long long)) == hipSuccess)
         (void)hipMemset(s->d_stats, 0, 16 * sizeof(unsigned long long));
     if (const char *e = std::getenv("NNBVH_STACK_WINDOW")) nnbvh_scene_set_option(s, "stack_window", atoi(e));
@@ -519,6 +561,21 @@ nnbvh_scene *nnbvh_scene_create_instanced(const nnbvh_linear_node *nodes, int n_
                         n_instances, device);
 }
 
+nnbvh_scene *nnbvh_scene_create_instanced_animated(const nnbvh_linear_node *nodes, int n_nodes,
+                                                   int n_top_nodes, const nnbvh_prim *prims, int n_prims,
+                                                   const float *verts, int n_verts,
+                                                   const nnbvh_instance *instances, int n_instances,
+                                                   const nnbvh_animated_transform *animated, int device) {
+    if (animated)
+        for (int k = 0; k < n_instances; ++k)
+            if (animated[k].actually_animated && !(animated[k].end_time > animated[k].start_time)) {
+                set_error("scene_create: animated instance with an empty time range");
+                return nullptr;
+            }
+    return create_scene(nodes, n_nodes, n_top_nodes, prims, n_prims, verts, n_verts, instances,
+                        n_instances, device, animated);
+}
+
 void nnbvh_transform_bounds(const float m[12], const float in[6], float out[6]) {
     // Transform::operator()(const Bounds3f&), util/transform.cpp:134-139: union of the 8
     // transformed corners (Bounds3::Corner, vecmath.h:1284-1289; point transform
@@ -559,6 +616,7 @@ void nnbvh_scene_destroy(nnbvh_scene *s) {
         if (p) (void)hipFree(p);
     (void)hipFree(s->d_wide);
     (void)hipFree(s->d_prims);
+    if (s->d_anim) (void)hipFree(s->d_anim);
     if (s->d_stats) (void)hipFree(s->d_stats);
     delete s;
 }
@@ -711,6 +769,9 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     p.intRepeat = s->int_repeat;
     p.hasHostPrims = s->has_host_prims;
     p.spill = w->spill;
+    p.anim = s->d_anim;
+    p.nBatches = 0;
+    p.anyMask = 0;
     if (!hip_ok(launch_zero_queue(w->queue, kMaxQueues * kQueueStrideWords, stream), "queue reset launch"))
         return NNBVH_ERR_DEVICE;
     // never launch more threads than there are rays to start with (tiny batches)
@@ -817,6 +878,7 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
         p.intRepeat = s->int_repeat;
         p.hasHostPrims = s->has_host_prims;
         p.spill = w->spill;
+        p.anim = s->d_anim;
         int64_t total = 0;
         for (int i = 0; i < n_batches; ++i) {
             if (batches[i].n == 0) continue;  // empty batches take no slot

@@ -34,6 +34,7 @@ struct TraceParams {
     int intRepeat;          // interior steps per scheduling decision (>= 1)
     unsigned long long *stats;  // NNBVH_STATS builds: trips/lanes per step kind; else unused
     uint2 *spill;           // [kMaxStack][grid threads] overflow of the LDS stack window
+    const float *anim;      // two-level scenes: kAnimStride floats per instance (anim_math.h), or null
     // mode 3 (one launch over several batches, closest-hit and occlusion-only any-hit mixed): batch
     // b's rays / results / size, queue heads at queue[(b * nQueues + q) * kQueueStrideWords]; bit b
     // of anyMask = batch b is any-hit (bOut = uint8 occluded[]), else closest (bOut = nnbvh_hit[])

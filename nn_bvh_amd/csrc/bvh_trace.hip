@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "bvh_trace.h"
+#include "anim_math.h"
 #include "spawn_math.h"
 #include "trace_math.h"
 
@@ -91,8 +92,8 @@ void trace_kernel(TraceParams p) {
     constexpr int kSaveO = kColdBase, kSaveInv = kColdBase + 3, kSaveShear = kColdBase + 6,
                   kSaveKz = kColdBase + 9, kSaveTmax = kColdBase + 10, kSaveD = kColdBase + 11,
                   kResume = kColdBase + 14, kCurInst = kColdBase + 15, kHitInst = kColdBase + 16,
-                  kInnerHit = kColdBase + 17;
-    constexpr int kColdFields = kColdBase + (INST ? 18 : 0);
+                  kInnerHit = kColdBase + 17, kColdTime = kColdBase + 18;
+    constexpr int kColdFields = kColdBase + (INST ? 19 : 0);
     __shared__ float s_cold[kBlockThreads / 64][kColdFields][64];
 
     const int lane = threadIdx.x & 63;
@@ -181,7 +182,10 @@ void trace_kernel(TraceParams p) {
         cold[kCurInst][lane] = __int_as_float(__float_as_int(s0.w) + 1);
         cold[kInnerHit][lane] = 0.0f;
         V3 oIn, dIn;
-        apply_inverse_ray(s2, s3, s4, r.o, dOuter, tMax, oIn, dIn);
+        float4 m0 = s2, m1 = s3, m2 = s4;
+        if ((flags & kPrimAnimated) && p.anim)  // AnimatedPrimitive: Interpolate(r.time), primitive.cpp:143-144
+            anim_inverse_rows(p.anim + (long)kAnimStride * __float_as_int(s0.w), cold[kColdTime][lane], m0, m1, m2);
+        apply_inverse_ray(m0, m1, m2, r.o, dOuter, tMax, oIn, dIn);
         r.o = oIn;
         cold[kColdD][lane] = dIn.x;
         cold[kColdD + 1][lane] = dIn.y;
@@ -356,6 +360,7 @@ void trace_kernel(TraceParams p) {
                 if (INST) {
                     cold[kHitInst][lane] = 0.0f;
                     cold[kCurInst][lane] = 0.0f;
+                    cold[kColdTime][lane] = r1.w;  // ray.time: read by animated instances
                     floor = -1;
                 }
                 if (p.hasHostPrims) cold[kColdHost][lane] = 0.0f;

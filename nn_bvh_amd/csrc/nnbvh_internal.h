@@ -49,6 +49,10 @@ constexpr uint32_t kPrimHost = 16u;
 // fourth word holds alpha; kPrimFlipN = mesh->reverseOrientation ^ mesh->transformSwapsHandedness
 constexpr uint32_t kPrimAlpha = 32u;
 constexpr uint32_t kPrimFlipN = 64u;
+// instance record of an AnimatedPrimitive: the inverse matrix is interpolated per ray from the
+// animation table (anim_math.h) instead of read from slots 2..4
+constexpr uint32_t kPrimAnimated = 128u;
+constexpr int kAnimStride = 76;  // floats per entry of the animation table (layout: anim_math.h)
 inline bool is_triangle_kind(int kind) {
     return kind == NNBVH_PRIM_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED;
 }

@@ -50,3 +50,116 @@ def test_interpolate_equals_reference_live(seed):
     a = anims_from_reference_output(rec, out)
     got = ob.anim_interpolate(a, rec[:, 34])
     assert np.array_equal(got.view(np.uint32), out[:, 80:112])
+
+
+# ---- the device's animated instances against the oracle ------------------------------------------
+def animated_scene(seed=2, n_place=30):
+    """One object (a bumpy grid) placed n_place times, two thirds of the placements animated
+    (AnimatedTransforms built by the REFERENCE's constructor where available, else taken from the
+    committed golden vectors); instance bounds = union of the bounds at many times, padded (the
+    caller's MotionBounds stand-in: any conservative box is a valid input)."""
+    import scenes_small as ss
+    from nn_bvh_amd import _lib, instancing
+    g = np.load(os.path.join(HERE, "golden", "anim_interpolate.npz"))
+    rec, out = g["inputs"], g["outputs"]
+    a_all = anims_from_reference_output(rec, out)
+    pick = np.nonzero(a_all["actually_animated"] != 0)[0]
+    rng = np.random.default_rng(seed)
+    pick = rng.choice(pick, n_place, replace=False)
+    verts, prims = ss.grid_mesh(10, seed)
+    anims = np.zeros(n_place, _lib.ANIMATED_DTYPE)
+    placements = []
+    for j, k in enumerate(pick):
+        a = a_all[k]
+        animated = j % 3 != 0
+        for src, dst in (("start_m", "start_from"), ("start_minv", "start_inv"), ("end_m", "end_from"), ("end_minv", "end_inv")):
+            anims[j][dst] = a[src]
+        anims[j]["T"], anims[j]["R"], anims[j]["S"] = a["T"], a["R"], a["S"]
+        anims[j]["start_time"], anims[j]["end_time"] = 0.0, 1.0
+        anims[j]["actually_animated"] = int(animated)
+        placements.append((0, a["start_m"][:12].copy(), a["start_minv"][:12].copy()))
+    nodes, aprims, instances, n_top = instancing.assemble_two_level(prims[:0], verts, [prims], placements)
+    # conservative bounds for the animated instances: sample Interpolate over the time range
+    oa = np.zeros(n_place, ob.ANIM_DTYPE)
+    for f_o, f_p in (("start_m", "start_from"), ("start_minv", "start_inv"), ("end_m", "end_from"), ("end_minv", "end_inv")):
+        oa[f_o] = anims[f_p]
+    for f in ("T", "R", "S", "start_time", "end_time", "actually_animated"):
+        oa[f] = anims[f]
+    return verts, prims, nodes, aprims, instances, n_top, anims, oa, placements
+
+
+def rebuild_with_motion_bounds(verts, prims, placements, anims, oa):
+    """Top-level tree over instance bounds that cover the whole motion."""
+    from nn_bvh_amd import build_tree, instancing
+    from nn_bvh_amd._lib import INSTANCE_DTYPE, PRIM_DTYPE
+    child = build_tree(prims, verts)
+    root = child.nodes[0]
+    box = np.concatenate([root["pmin"], root["pmax"]])
+    n = len(placements)
+    bounds = np.zeros((n, 6), np.float32)
+    for j in range(n):
+        lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+        times = np.linspace(0, 1, 33) if anims[j]["actually_animated"] else [0.0]
+        for t in times:
+            m = ob.anim_interpolate(oa[j:j + 1], [t])[0, :16].reshape(4, 4)
+            b = instancing.transform_bounds(m[:3].reshape(12), box)
+            lo, hi = np.minimum(lo, b[:3]), np.maximum(hi, b[3:])
+        pad = 0.05 * (hi - lo) + 1e-3
+        bounds[j] = np.concatenate([lo - pad, hi + pad])
+    inst_prims = np.zeros(n, PRIM_DTYPE)
+    inst_prims["kind"], inst_prims["id"] = 2, np.arange(n)
+    inst_prims["v"][:, 0] = np.arange(n)
+    top = build_tree(inst_prims, verts, prim_bounds=bounds)
+    cn = child.nodes.copy()
+    interior = cn["nprims"] == 0
+    cn["offset"][interior] += len(top.nodes)
+    cn["offset"][~interior] += len(top.ordered_prims)
+    nodes = np.concatenate([top.nodes, cn])
+    aprims = np.concatenate([top.ordered_prims, child.ordered_prims])
+    instances = np.zeros(n, INSTANCE_DTYPE)
+    for j, (_, m, mi) in enumerate(placements):
+        instances[j]["render_from_prim"], instances[j]["prim_from_render"] = m, mi
+        instances[j]["root"], instances[j]["n_nodes"] = len(top.nodes), len(cn)
+    return nodes, aprims, instances, len(top.nodes)
+
+
+def test_oracle_animated_instances_reduce_to_static_ones_at_the_time_range_ends():
+    from nn_bvh_amd import scene
+    verts, prims, _, _, _, _, anims, oa, placements = animated_scene()
+    nodes, aprims, instances, n_top = rebuild_with_motion_bounds(verts, prims, placements, anims, oa)
+    rays = scene.random_rays(6000, [-25, -25, -25], [25, 25, 25], 3)
+    rays["time"] = 0.0
+    h0 = ob.closest_anim(nodes, aprims, verts, instances, oa, rays, 4)
+    hs = ob.closest_inst(nodes, aprims, verts, instances, rays, 4)  # static = the start transforms
+    assert h0.tobytes() == hs.tobytes() and (h0["instance"] > 0).sum() > 100
+    rays["time"] = 0.5
+    h5 = ob.closest_anim(nodes, aprims, verts, instances, oa, rays, 4)
+    assert (h5["prim"] != h0["prim"]).mean() > 0.02  # the animated instances have moved
+
+
+@pytest.mark.gpu
+def test_device_animated_instances_equal_the_oracle():
+    """Bit-equality is the expectation; the documented exception (fp64-rounded sine vs libm's sinf in
+    Slerp, about one differing input in 10^5) may flip a handful of rays."""
+    from nn_bvh_amd import BVHAggregate, scene
+    verts, prims, _, _, _, _, anims, oa, placements = animated_scene(4, 36)
+    nodes, aprims, instances, n_top = rebuild_with_motion_bounds(verts, prims, placements, anims, oa)
+    agg = BVHAggregate.from_tree(nodes, aprims, verts, instances=instances, n_top_nodes=n_top, animated=anims)
+    n = 60000
+    rays = scene.random_rays(n, [-25, -25, -25], [25, 25, 25], 5)
+    rays["time"] = np.random.default_rng(6).uniform(-0.2, 1.2, n).astype(np.float32)
+    got = agg.Intersect(rays)
+    exp = ob.closest_anim(nodes, aprims, verts, instances, oa, rays, 4)
+    same = got.view(np.uint8).reshape(n, 32) == exp.view(np.uint8).reshape(n, 32)
+    diff = np.nonzero(~same.all(1))[0]
+    assert len(diff) <= 0.0005 * n, f"{len(diff)} of {n} rays differ"
+    assert (exp["instance"] > 0).mean() > 0.15
+    inside = (rays["time"] > 0) & (rays["time"] < 1)
+    moved = anims["actually_animated"][np.maximum(exp["instance"] - 1, 0)] != 0
+    assert ((exp["instance"] > 0) & inside & moved).sum() > 2000  # the interpolation path is exercised
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    eo, ev, et = ob.any_hit_anim(nodes, aprims, verts, instances, oa, rays, 4)
+    bad = (occ != eo) | (vis != ev) | (tst != et)
+    assert bad.sum() <= 0.0005 * n
+    print(f"animated instances: {len(diff)} closest-hit and {int(bad.sum())} any-hit records of {n} differ")
+    agg.close()
