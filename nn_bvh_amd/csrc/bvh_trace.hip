@@ -472,6 +472,14 @@ void trace_kernel(TraceParams p) {
                 st[15] += __popcll(__ballot(cur >= 0));
 #endif
                 if (cur < 0) continue;
+#ifdef NNBVH_PROBE_SALU  // sensitivity probes (tools only): extra scalar / vector instructions per interior step
+#pragma unroll
+                for (int k = 0; k < NNBVH_PROBE_SALU; ++k) asm volatile("s_add_u32 s95, s95, 1" ::: "s95", "scc");
+#endif
+#ifdef NNBVH_PROBE_VALU
+#pragma unroll
+                for (int k = 0; k < NNBVH_PROBE_VALU; ++k) asm volatile("v_add_u32 %0, %0, 1" : "+v"(tests));
+#endif
                 const float4 *rec = p.wide + 4 * (long)cur;
                 const float4 q3 = rec[3];
                 const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];

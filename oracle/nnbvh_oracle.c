@@ -521,6 +521,15 @@ static int mat4_inverse(const float mm[16], float out[16]) {
     return 1;
 }
 
+/* 0 = libm's sinf, as the reference; 1 = sine evaluated in double and rounded once, as the device's
+ * Slerp does (the documented tolerance exception of AnimatedPrimitive).  Only the per-ray
+ * sines of Interpolate are switched; theta and SinXOverX(theta) are host-side libm values in both. */
+static int g_sin_mode = 0;
+void orc_set_sin_mode(int mode) { g_sin_mode = mode; }
+static float sin_x_over_x_ray(float x) { /* util/math.h:340-344 */
+    if (1 - x * x == 1) return 1;
+    return (g_sin_mode ? (float)sin((double)x) : sinf(x)) / x;
+}
 static float sin_x_over_x(float x) { /* util/math.h:340-344 */
     if (1 - x * x == 1) return 1;
     return sinf(x) / x;
@@ -559,7 +568,7 @@ void orc_anim_interpolate(const orc_anim *a, float time, float m[16], float minv
     /* Slerp(dt, R[0], R[1]), vecmath.h:1146-1151 */
     const float theta = quat_angle_between(a->R[0], a->R[1]);
     const float sinThetaOverTheta = sin_x_over_x(theta);
-    const float w1 = sin_x_over_x((1 - dt) * theta), w2 = sin_x_over_x(dt * theta);
+    const float w1 = sin_x_over_x_ray((1 - dt) * theta), w2 = sin_x_over_x_ray(dt * theta);
     float q[4];
     for (int k = 0; k < 4; ++k)
         q[k] = a->R[0][k] * (1 - dt) * w1 / sinThetaOverTheta + a->R[1][k] * dt * w2 / sinThetaOverTheta;

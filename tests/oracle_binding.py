@@ -320,3 +320,8 @@ def any_hit_anim(nodes, prims, verts, instances, anims, rays, nthreads=1):
     lib().orc_intersect_any_anim(_p(nodes), _p(prims), _p(verts), _p(inst), _p(an), _p(rays),
                                  ctypes.c_int64(len(rays)), _p(occ), _p(vis), _p(tst), ctypes.c_int(nthreads))
     return occ, vis, tst
+
+
+def set_sin_mode(mode):
+    """0: Slerp's per-ray sines with libm's sinf (the reference); 1: fp64 sine rounded once (the device)."""
+    lib().orc_set_sin_mode(ctypes.c_int(mode))
