@@ -488,6 +488,31 @@ void trace_kernel(TraceParams p) {
                 // aggregates.cpp:562-568: near child = second child iff dirIsNeg[axis]
                 const bool swap = (axis == 0 ? r.inv.x : (axis == 1 ? r.inv.y : r.inv.z)) < 0.0f;
                 float t0, t1;
+#ifdef NNBVH_VALU_LOGIC
+                // verdicts as 0 / 1 integers in VGPRs and a push without a branch: the scalar unit, which
+                // this kernel keeps busier than the vector ALUs, drops out of the step's boolean algebra
+                const unsigned b0 = slab_partial_bits(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, t0);
+                const unsigned b1 = slab_partial_bits(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, t1);
+                const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
+                const unsigned nearB = swap ? b1 : b0, farB = swap ? b0 : b1;
+                const float nearT = swap ? t1 : t0, farT = swap ? t0 : t1;
+                const bool nearE = nearB != 0u, farE = farB != 0u;
+                visited += 1;  // the near child is entered now
+                const bool doPush = (MODE == 1) || farE;
+                // the window is kept at most W - 1 deep, so slot `sp` is always free and the far child can
+                // be written there unconditionally; it only counts if sp moves past it
+                if (doPush && sp - base == W - 1) {
+                    uint2 e;
+                    e.x = (unsigned)sref[base & (W - 1)][lane];
+                    e.y = __float_as_uint(skey[base & (W - 1)][lane]);
+                    p.spill[(long)base * spillStride + gtid] = e;
+                    ++base;
+                }
+                sref[sp & (W - 1)][lane] = farRef;
+                skey[sp & (W - 1)][lane] = farE ? farT : __builtin_inff();
+                sp += doPush ? 1 : 0;
+                if (MODE == 0 || MODE == 3) visited += doPush ? 0 : 1;  // popped and rejected later: same count
+#else
                 const bool e0 = slab_partial(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, t0);
                 const bool e1 = slab_partial(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, t1);
                 const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
@@ -509,6 +534,7 @@ void trace_kernel(TraceParams p) {
                 } else if (MODE == 0 || MODE == 3) {
                     visited += 1;  // the reference pops and rejects it later: same count
                 }
+#endif
                 if (nearE && nearT < tMax) cur = nearRef;
                 else cur = pop_next();
             }
