@@ -63,6 +63,12 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 #ifndef NNBVH_LEAN_EXTRA_WAVES
 #define NNBVH_LEAN_EXTRA_WAVES 0
 #endif
+// The interior step keeps its box-test verdicts as 0 / 1 integers in VGPRs and pushes without a branch
+// (measured +0.6 .. 1.9 % per ray class and 8 VGPRs fewer than combining compare masks on the scalar
+// unit; -DNNBVH_SCALAR_LOGIC builds the earlier form for comparison)
+#ifndef NNBVH_SCALAR_LOGIC
+#define NNBVH_VALU_LOGIC 1
+#endif
 //
 // INST = 1: the scene is two-level (TransformedPrimitive leaves, cpu/primitive.cpp:112-131).  An
 // instance primitive saves the lane's ray state in LDS, transforms the ray with the reference's
