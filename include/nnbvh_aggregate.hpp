@@ -4,9 +4,12 @@
 //   per-ray     Primitive::{Bounds, Intersect, IntersectP}
 //               (/root/reference/src/pbrt/cpu/primitive.h:33-45; BVHAggregate's versions at
 //                cpu/aggregates.h:28-70, cpu/aggregates.cpp:524-624)
-//   batched     WavefrontAggregate::{Bounds, IntersectClosest, IntersectShadow}
+//   batched     WavefrontAggregate::{Bounds, IntersectClosest, IntersectShadow, IntersectShadowTr,
+//               IntersectOneRandom}
 //               (/root/reference/src/pbrt/wavefront/integrator.h:32-54; CPU implementation
-//                wavefront/aggregate.cpp:34-68)
+//                wavefront/aggregate.cpp:34-116; the last two in their media-free form)
+//   kd-tree     KdTreeAggregate (cpu/aggregates.h:75-105) as HipKdTreeAggregate
+//   film        RGBFilm's accumulators (film.h:232-316) as HipFilm
 //
 // The class owns only the opaque scene handle.  Error behaviour mirrors the reference: pbrt
 // aborts through CHECK / LOG_FATAL (util/check.h:36-57, cpu/aggregates.cpp:145); here every
@@ -166,6 +169,34 @@ class HipBVHAggregate {
             fatal("IntersectShadowQueue");
     }
 
+    // == one wavefront iteration's independent queues as ONE launch (include/nnbvh.h)
+    void TraceBatchesDevice(const nnbvh_batch *batches, int nBatches, void *stream) const {
+        if (nnbvh_trace_batches_device(scene_, batches, nBatches, stream) != NNBVH_OK)
+            fatal("TraceBatchesDevice");
+    }
+    // == WavefrontAggregate::IntersectShadowTr (wavefront/integrator.h:48-49), scenes without media
+    void IntersectShadowTrQueue(const nnbvh_shading_mesh *mesh, int maxRays, const nnbvh_ray_soa &shadowQueue,
+                                const int32_t *dSize, const uint8_t *dPrimClass, int64_t nPrimClass,
+                                const float *dLd, const float *dRu, const float *dRl,
+                                const int32_t *dPixelIndex, float *dL, int64_t nPixels, void *stream,
+                                uint8_t *dState = nullptr) const {
+        if (nnbvh_wavefront_intersect_shadow_tr(scene_, mesh, maxRays, &shadowQueue, dSize, dPrimClass,
+                                                nPrimClass, dLd, dRu, dRl, dPixelIndex, dL, nPixels, dState,
+                                                stream) != NNBVH_OK)
+            fatal("IntersectShadowTrQueue");
+    }
+    // == WavefrontAggregate::IntersectOneRandom (wavefront/integrator.h:51-52)
+    void IntersectOneRandomQueue(const nnbvh_shading_mesh *mesh, int maxItems, const float *dP0,
+                                 const float *dP1, const int32_t *dMaterial, const int32_t *dSize,
+                                 const int32_t *dPrimMaterial, int64_t nPrimMaterial, void *dSelHits,
+                                 void *dSelRays, float *dReservoirPdf, void *stream,
+                                 float *dWeightSum = nullptr) const {
+        if (nnbvh_wavefront_intersect_one_random(scene_, mesh, maxItems, dP0, dP1, dMaterial, dSize,
+                                                 dPrimMaterial, nPrimMaterial, dSelHits, dSelRays,
+                                                 dReservoirPdf, dWeightSum, stream) != NNBVH_OK)
+            fatal("IntersectOneRandomQueue");
+    }
+
     nnbvh_scene *handle() const { return scene_; }
 
   private:
@@ -204,8 +235,123 @@ class HipShadingMesh {
             HipBVHAggregate::fatal("InteractionsDevice");
     }
 
+    nnbvh_shading_mesh *handle() const { return mesh_; }
+
   private:
     nnbvh_shading_mesh *mesh_ = nullptr;
+};
+
+// KdTreeAggregate (cpu/aggregates.h:75-105): Create's parameters (aggregates.cpp:1152-1161) and the
+// Primitive-shaped methods; batches as for HipBVHAggregate.
+class HipKdTreeAggregate {
+  public:
+    HipKdTreeAggregate(const std::vector<nnbvh_prim> &prims, const std::vector<float> &verts,
+                       int isectCost = 5, int traversalCost = 1, float emptyBonus = 0.5f, int maxPrims = 1,
+                       int maxDepth = -1, int device = 0) {
+        nnbvh_kd_build *b = nnbvh_kd_build_create(prims.data(), (int)prims.size(), verts.data(),
+                                                  (int)(verts.size() / 3), nullptr, isectCost, traversalCost,
+                                                  emptyBonus, maxPrims, maxDepth);
+        if (!b) {
+            HipBVHAggregate::fatal("HipKdTreeAggregate: build");
+            return;
+        }
+        int nNodes = 0, nIdx = 0;
+        const nnbvh_kd_node *nodes = nnbvh_kd_build_nodes(b, &nNodes);
+        const int32_t *idx = nnbvh_kd_build_prim_indices(b, &nIdx);
+        nnbvh_kd_build_bounds(b, bounds_);
+        scene_ = nnbvh_kd_scene_create(nodes, nNodes, idx, nIdx, prims.data(), (int)prims.size(), verts.data(),
+                                       (int)(verts.size() / 3), bounds_, device);
+        nnbvh_kd_build_destroy(b);
+        if (!scene_) HipBVHAggregate::fatal("HipKdTreeAggregate: scene_create");
+    }
+    // from a tree pbrt itself built: KdTreeAggregate::nodes, primitiveIndices, primitives, bounds
+    HipKdTreeAggregate(const nnbvh_kd_node *nodes, int nNodes, const int32_t *primIndices, int nIndices,
+                       const nnbvh_prim *prims, int nPrims, const float *verts, int nVerts,
+                       const float boundsMinMax[6], int device = 0) {
+        for (int k = 0; k < 6; ++k) bounds_[k] = boundsMinMax[k];
+        scene_ = nnbvh_kd_scene_create(nodes, nNodes, primIndices, nIndices, prims, nPrims, verts, nVerts,
+                                       boundsMinMax, device);
+        if (!scene_) HipBVHAggregate::fatal("HipKdTreeAggregate: scene_create");
+    }
+    HipKdTreeAggregate(const HipKdTreeAggregate &) = delete;
+    HipKdTreeAggregate &operator=(const HipKdTreeAggregate &) = delete;
+    ~HipKdTreeAggregate() { nnbvh_kd_scene_destroy(scene_); }
+
+    Bounds3f Bounds() const { return {{bounds_[0], bounds_[1], bounds_[2]}, {bounds_[3], bounds_[4], bounds_[5]}}; }
+    std::optional<HitRecord> Intersect(const Ray &ray, float tMax = std::numeric_limits<float>::infinity()) const {
+        nnbvh_ray r{{ray.o.x, ray.o.y, ray.o.z}, tMax, {ray.d.x, ray.d.y, ray.d.z}, ray.time};
+        nnbvh_hit h;
+        if (nnbvh_kd_intersect_closest(scene_, &r, 1, &h) != NNBVH_OK) HipBVHAggregate::fatal("kd Intersect");
+        if (h.prim < 0) return {};
+        return HitRecord{h.prim, h.t, h.b0, h.b1, h.b2};
+    }
+    bool IntersectP(const Ray &ray, float tMax = std::numeric_limits<float>::infinity()) const {
+        nnbvh_ray r{{ray.o.x, ray.o.y, ray.o.z}, tMax, {ray.d.x, ray.d.y, ray.d.z}, ray.time};
+        uint8_t occ = 0;
+        if (nnbvh_kd_intersect_any(scene_, &r, 1, &occ, nullptr, nullptr) != NNBVH_OK)
+            HipBVHAggregate::fatal("kd IntersectP");
+        return occ != 0;
+    }
+    void IntersectClosest(const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits) const {
+        if (nnbvh_kd_intersect_closest(scene_, rays, n, hits) != NNBVH_OK) HipBVHAggregate::fatal("kd IntersectClosest");
+    }
+    void IntersectShadow(const nnbvh_ray *rays, int64_t n, uint8_t *occluded, int32_t *nodesVisited = nullptr,
+                         int32_t *primTests = nullptr) const {
+        if (nnbvh_kd_intersect_any(scene_, rays, n, occluded, nodesVisited, primTests) != NNBVH_OK)
+            HipBVHAggregate::fatal("kd IntersectShadow");
+    }
+    void IntersectClosestDevice(const void *dRays, int64_t n, void *dHits, void *stream) const {
+        if (nnbvh_kd_intersect_closest_device(scene_, dRays, n, dHits, stream) != NNBVH_OK)
+            HipBVHAggregate::fatal("kd IntersectClosestDevice");
+    }
+    void IntersectShadowDevice(const void *dRays, int64_t n, void *dOccluded, void *stream,
+                               void *dNodesVisited = nullptr, void *dPrimTests = nullptr) const {
+        if (nnbvh_kd_intersect_any_device(scene_, dRays, n, dOccluded, dNodesVisited, dPrimTests, stream) != NNBVH_OK)
+            HipBVHAggregate::fatal("kd IntersectShadowDevice");
+    }
+
+  private:
+    nnbvh_kd_scene *scene_ = nullptr;
+    float bounds_[6] = {0, 0, 0, 0, 0, 0};
+};
+
+// RGBFilm's pixel accumulators (film.h:232-316): AddSample as UpdateFilm calls it, read-back, and the
+// pack / unpack halves of a tile all-gather.
+class HipFilm {
+  public:
+    HipFilm(int x0, int y0, int x1, int y1, float maxComponentValue = std::numeric_limits<float>::infinity(),
+            int device = 0)
+        : film_(nnbvh_film_create(x0, y0, x1, y1, maxComponentValue, device)), nPixels_((int64_t)(x1 - x0) * (y1 - y0)) {
+        if (!film_) HipBVHAggregate::fatal("HipFilm");
+    }
+    ~HipFilm() { nnbvh_film_destroy(film_); }
+    HipFilm(const HipFilm &) = delete;
+    HipFilm &operator=(const HipFilm &) = delete;
+
+    void AddSamplesDevice(const int32_t *dPx, const int32_t *dPy, const float *dRgb, int rgbStride,
+                          const float *dWeight, int nPerPass, int nPasses, const int32_t *dSize, void *stream) {
+        if (nnbvh_film_add_samples_device(film_, dPx, dPy, dRgb, rgbStride, dWeight, nPerPass, nPasses, dSize,
+                                          stream) != NNBVH_OK)
+            HipBVHAggregate::fatal("HipFilm::AddSamplesDevice");
+    }
+    std::vector<double> Read() {  // 4 doubles per pixel: rgbSum[3], weightSum
+        std::vector<double> out((size_t)nPixels_ * 4);
+        if (nnbvh_film_read(film_, out.data()) != NNBVH_OK) HipBVHAggregate::fatal("HipFilm::Read");
+        return out;
+    }
+    void PackPixelsDevice(const int32_t *dIndex, int64_t n, void *dOut, void *stream) {
+        if (nnbvh_film_pack_pixels_device(film_, dIndex, n, dOut, stream) != NNBVH_OK)
+            HipBVHAggregate::fatal("HipFilm::PackPixelsDevice");
+    }
+    void UnpackPixelsDevice(const int32_t *dIndex, int64_t n, const void *dIn, void *stream) {
+        if (nnbvh_film_unpack_pixels_device(film_, dIndex, n, dIn, stream) != NNBVH_OK)
+            HipBVHAggregate::fatal("HipFilm::UnpackPixelsDevice");
+    }
+    nnbvh_film *handle() const { return film_; }
+
+  private:
+    nnbvh_film *film_ = nullptr;
+    int64_t nPixels_ = 0;
 };
 
 }  // namespace nnbvh

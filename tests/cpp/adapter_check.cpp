@@ -72,6 +72,23 @@ int main() {
         float n2 = intr[i].n[0] * intr[i].n[0] + intr[i].n[1] * intr[i].n[1] + intr[i].n[2] * intr[i].n[2];
         if (std::fabs(n2 - 1) > 1e-5f) return 8;
     }
+    // the other accelerator through the same Primitive-shaped interface: same hits, same t
+    nnbvh::HipKdTreeAggregate kd(prims, verts);  // KdTreeAggregate::Create's defaults
+    std::vector<nnbvh_hit> kdHits(nRays);
+    kd.IntersectClosest(rays.data(), nRays, kdHits.data());
+    for (int i = 0; i < nRays; ++i) {
+        if ((kdHits[i].prim >= 0) != (hits[i].prim >= 0)) return 11;
+        if (hits[i].prim >= 0 && std::memcmp(&kdHits[i].t, &hits[i].t, 4)) return 12;
+        nnbvh::Ray ray{{rays[i].o[0], rays[i].o[1], rays[i].o[2]}, {rays[i].d[0], rays[i].d[1], rays[i].d[2]}, 0};
+        if (kd.IntersectP(ray) != (occ[i] != 0)) return 13;
+    }
+    if (!(kd.Bounds().pMin.x <= b.pMin.x + 1e-6f)) return 14;
+    // the film: an empty film reads back as zeros (accumulation itself: tests/test_film.py)
+    nnbvh::HipFilm film(0, 0, 8, 4);
+    std::vector<double> px = film.Read();
+    if (px.size() != 8 * 4 * 4) return 15;
+    for (double v : px)
+        if (v != 0.0) return 16;
     std::printf("adapter ok: %d rays, %d hits\n", nRays, nHit);
     return nHit > 0 ? 0 : 4;
 }
