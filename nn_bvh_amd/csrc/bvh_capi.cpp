@@ -81,6 +81,7 @@ struct nnbvh_scene {
     int has_alpha = 0;      // alpha-tested triangles present: the ALPHA kernels run
     int fused_batches = 1;  // nnbvh_trace_batches_device: one mode-3 launch where the batches allow it
     int int_repeat = 3;
+    int prim_repeat = 2;
     int max_grid_threads = 0;
     double build_ms[1] = {0};  // device build time of nnbvh_scene_create_gpu_build
     std::mutex mu;
@@ -703,6 +704,12 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
             return NNBVH_ERR_ARG;
         }
         s->int_repeat = value;
+    } else if (k == "prim_repeat") {
+        if (value < 1 || value > 16) {
+            set_error("set_option: prim_repeat must be 1..16");
+            return NNBVH_ERR_ARG;
+        }
+        s->prim_repeat = value;
     } else if (k == "fused_batches") {
         s->fused_batches = value ? 1 : 0;
     } else if (k == "xcd_queues") {
@@ -767,6 +774,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     p.refillWeight = s->refill_weight;
     p.stats = s->d_stats;
     p.intRepeat = s->int_repeat;
+    p.primRepeat = s->prim_repeat;
     p.hasHostPrims = s->has_host_prims;
     p.spill = w->spill;
     p.anim = s->d_anim;
@@ -876,6 +884,7 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
         p.refillWeight = s->refill_weight;
         p.stats = s->d_stats;
         p.intRepeat = s->int_repeat;
+        p.primRepeat = s->prim_repeat;
         p.hasHostPrims = s->has_host_prims;
         p.spill = w->spill;
         p.anim = s->d_anim;

@@ -386,7 +386,11 @@ void trace_kernel(TraceParams p) {
 
         if (sP > sI || nInt == 0) {
             // ---- primitive step: lanes with a pending leaf test ONE primitive -----------
-            if (!isInt && !isIdle) {
+            // (up to p.primRepeat of them per scheduling decision: lanes whose leaf is finished sit the
+            // rest out, lanes still inside theirs go on without another round of ballots)
+            for (int prep = 0; prep < p.primRepeat; ++prep) {
+            if (prep > 0 && __ballot(cur < 0 && cur != kDone) == 0ull) break;
+            if (cur < 0 && cur != kDone) {
                 if (INST && cur == kReturn) leave_instance();
                 if (cur < 0 && cur != kDone && cur != kReturn) {
                     const int slot = ~cur;
@@ -467,6 +471,7 @@ void trace_kernel(TraceParams p) {
                         else cur = ~next;
                     }
                 }
+            }
             }
         } else {
             // ---- interior step(s): up to p.intRepeat in a row before the next scheduling

@@ -131,7 +131,8 @@ def test_results_independent_of_tuning_and_order():
     assert (shuffled.tobytes() == base[perm].tobytes())
     for key, val in (("xcd_queues", 0), ("refill_weight", 1), ("refill_weight", 64),
                      ("prim_weight", 1), ("prim_weight", 64), ("blocks_per_cu", 1),
-                     ("stack_window", 4), ("int_repeat", 1), ("int_repeat", 5)):
+                     ("stack_window", 4), ("int_repeat", 1), ("int_repeat", 5), ("prim_repeat", 1),
+                     ("prim_repeat", 4)):
         agg.set_option(key, val)
         assert agg.Intersect(rays).tobytes() == base.tobytes(), f"{key}={val} changed results"
     agg.close()

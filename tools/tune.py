@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--xcd", default="1")
     ap.add_argument("--minwaves", default="0")
     ap.add_argument("--intrepeat", default="1")
+    ap.add_argument("--primrepeat", default="2")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--repeat", type=int, default=1, help="concatenate each batch this many times")
     args = ap.parse_args()
@@ -56,7 +57,7 @@ def main():
                                     [int(x) for x in args.xcd.split(",")],
                                     [int(x) for x in args.primat.split(",")],
                                     [int(x) for x in args.minwaves.split(",")],
-                                    [0],
+                                    [int(x) for x in args.primrepeat.split(",")],
                                     [int(x) for x in args.intrepeat.split(",")]))
     times = {c: {k: [] for k in d} for c in combos}
 
@@ -74,6 +75,7 @@ def main():
             agg.set_option("xcd_queues", c[3])
             agg.set_option("prim_weight", c[4])
             agg.set_option("int_repeat", c[7])
+            agg.set_option("prim_repeat", c[6])
             for kind in d:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
@@ -101,7 +103,7 @@ def main():
                 elif args.stats:
                     agg.sched_stats()
     print(f"# {source}; rays: {n}")
-    print("window blocks refillw xcd primw minw pf rep | primary bounce shadow  Mray/s (median)")
+    print("window blocks refillw xcd primw minw prep irep | primary bounce shadow  Mray/s (median)")
     for c in combos:
         r = [n[k] / np.median(times[c][k]) / 1e3 for k in ("primary", "bounce", "shadow")]
         print(f"{c[0]:6d} {c[1]:6d} {c[2]:6d} {c[3]:3d} {c[4]:6d} {c[5]:4d} {c[6]:2d} {c[7]:3d} | {r[0]:7.1f} {r[1]:7.1f} {r[2]:7.1f}", flush=True)
