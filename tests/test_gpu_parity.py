@@ -461,4 +461,17 @@ def test_device_entry_points_are_hip_graph_capturable():
         assert torch.equal(d_hits, eager_hits) and torch.equal(d_occ, eager_occ)
     exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, nthreads=8)
     assert_hits_equal(d_hits.cpu().numpy().view(exp.dtype), exp, "graph replay")
+    # the one-launch form of the same iteration (mode-3 kernel) captures and replays as well
+    def fused(stream):
+        agg.trace_batches_device([("closest", d_rays.data_ptr(), len(rays), d_hits.data_ptr()),
+                                  ("any", d_shadow.data_ptr(), len(rays), d_occ.data_ptr())], stream)
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=side):
+        fused(side.cuda_stream)
+    d_hits.zero_()
+    d_occ.zero_()
+    torch.cuda.synchronize()
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(d_hits, eager_hits) and torch.equal(d_occ, eager_occ)
     agg.close()
