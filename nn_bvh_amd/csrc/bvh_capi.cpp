@@ -638,6 +638,7 @@ static int grid_blocks(nnbvh_scene *s, int mode) {
     int per_cu = s->blocks_per_cu;
     if (per_cu <= 0) {
         TraceParams dummy{};
+        dummy.hasHostPrims = s->has_host_prims;  // selects between the lean and the general instances
         int occ = 0;
         if (launch_trace(mode, dummy, s->window, s->instanced, s->has_patches + 2 * s->has_alpha, 0, nullptr, &occ) != hipSuccess ||
             occ <= 0)

@@ -61,7 +61,7 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 #define NNBVH_MINW_ANY 6
 #endif
 #ifndef NNBVH_LEAN_EXTRA_WAVES
-#define NNBVH_LEAN_EXTRA_WAVES 0
+#define NNBVH_LEAN_EXTRA_WAVES 2
 #endif
 // The interior step keeps its box-test verdicts as 0 / 1 integers in VGPRs and pushes without a branch
 // (measured +0.6 .. 1.9 % per ray class and 8 VGPRs fewer than combining compare masks on the scalar
@@ -92,15 +92,21 @@ void trace_kernel(TraceParams p) {
     // ray index (read when the ray retires), the direction (read by the patch test only; the
     // triangle test uses the precomputed shear) and, closest hit, the current best hit
     // (written on an accepted hit, read at retire).  Frees 4 / 8 registers per lane.
-    constexpr int kColdRi = 0, kColdD = 1, kColdHit = PATCH ? 4 : 1, kColdHost = kColdHit + ((MODE == 0 || MODE == 3) ? 4 : 0);
-    constexpr int kColdBase = kColdHost + 1;  // kColdHost: the ray reached a host-only primitive
+    // The lean instances (PATCH = 0: no patches, no instances, and — the launcher sees to it — no
+    // host-only primitives) keep the ray index in a VGPR and have no host flag: the closest-hit kernel's
+    // cold state is then the four hit words, 20 KiB of LDS per block with the stack window, which is
+    // what lets an EIGHTH block share the CU's 160 KiB (its 61 VGPRs allow 8 wavefronts per SIMD).
+    constexpr bool kLean = !PATCH && !INST;
+    constexpr int kColdRi = 0, kColdD = 1, kColdHit = kLean ? 0 : (PATCH ? 4 : 1),
+                  kColdHost = kColdHit + ((MODE == 0 || MODE == 3) ? 4 : 0);
+    constexpr int kColdBase = kColdHost + (kLean ? 0 : 1);  // kColdHost: the ray reached a host-only primitive
     // two-level scenes: the outer ray saved while a child tree is traversed
     constexpr int kSaveO = kColdBase, kSaveInv = kColdBase + 3, kSaveShear = kColdBase + 6,
                   kSaveKz = kColdBase + 9, kSaveTmax = kColdBase + 10, kSaveD = kColdBase + 11,
                   kResume = kColdBase + 14, kCurInst = kColdBase + 15, kHitInst = kColdBase + 16,
                   kInnerHit = kColdBase + 17, kColdTime = kColdBase + 18;
     constexpr int kColdFields = kColdBase + (INST ? 19 : 0);
-    __shared__ float s_cold[kBlockThreads / 64][kColdFields][64];
+    __shared__ float s_cold[kBlockThreads / 64][kColdFields > 0 ? kColdFields : 1][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -108,7 +114,8 @@ void trace_kernel(TraceParams p) {
     int(*sref)[64] = s_ref[wave];
     float(*skey)[64] = s_key[wave];
     float(*cold)[64] = s_cold[wave];
-    cold[kColdRi][lane] = __int_as_float(-1);  // ray this lane carries, -1 = none
+    int riReg = -1;  // lean instances: the ray this lane carries, -1 = none
+    if (!kLean) cold[kColdRi][lane] = __int_as_float(-1);
     const long spillStride = (long)gridDim.x * kBlockThreads;
 
     // which queue this wave drains first: its XCD's share of the batch (speed only)
@@ -262,12 +269,12 @@ void trace_kernel(TraceParams p) {
 #endif
         if (nIdle == 64 || (sR > sI && sR > sP)) {
             // ---- retire finished rays, refill idle lanes -------------------------------
-            const int ri = isIdle ? __float_as_int(cold[kColdRi][lane]) : -1;
+            const int ri = isIdle ? (kLean ? riReg : __float_as_int(cold[kColdRi][lane])) : -1;
             if (MODE == 3 && ri >= 0) {
                 const int b = ri >> kFusedIndexBits;
                 const long idx = ri & ((1 << kFusedIndexBits) - 1);
                 void *outp = b == 0 ? p.bOut[0] : (b == 1 ? p.bOut[1] : (b == 2 ? p.bOut[2] : p.bOut[3]));
-                const bool needHost = p.hasHostPrims && cold[kColdHost][lane] != 0.0f;
+                const bool needHost = !kLean && p.hasHostPrims && cold[kColdHost][lane] != 0.0f;
                 if ((p.anyMask >> b) & 1u) {
                     reinterpret_cast<uint8_t *>(outp)[idx] = found ? 1 : (needHost ? 2 : 0);
                 } else {
@@ -296,12 +303,12 @@ void trace_kernel(TraceParams p) {
                     h1.y = __int_as_float(visited);
                     h1.z = __int_as_float(tests);
                     h1.w = INST ? cold[kHitInst][lane] : 0.0f;  // 0 / instance index + 1 (bit pattern)
-                    if (p.hasHostPrims && cold[kColdHost][lane] != 0.0f) h1.w = __int_as_float(-1);
+                    if (!kLean && p.hasHostPrims && cold[kColdHost][lane] != 0.0f) h1.w = __int_as_float(-1);
                     float4 *out = reinterpret_cast<float4 *>(p.hits) + 2 * (long)ri;
                     out[0] = h0;
                     out[1] = h1;
                 } else {
-                    const bool needHost = p.hasHostPrims && cold[kColdHost][lane] != 0.0f;
+                    const bool needHost = !kLean && p.hasHostPrims && cold[kColdHost][lane] != 0.0f;
                     p.occluded[ri] = found ? 1 : (needHost ? 2 : 0);
                     if (MODE == 1) {
                         if (p.visitedOut) p.visitedOut[ri] = visited;
@@ -339,9 +346,11 @@ void trace_kernel(TraceParams p) {
                 }
                 q = (q + 1 == p.nQueues) ? 0 : q + 1;
             }
-            if (isIdle)
-                cold[kColdRi][lane] =
-                    __int_as_float((MODE == 3 && newRi >= 0) ? (newRi | (curBatch << kFusedIndexBits)) : newRi);
+            if (isIdle) {
+                const int tag = (MODE == 3 && newRi >= 0) ? (newRi | (curBatch << kFusedIndexBits)) : newRi;
+                if (kLean) riReg = tag;
+                else cold[kColdRi][lane] = __int_as_float(tag);
+            }
             if (newRi >= 0) {
                 const nnbvh_ray *batchRays = MODE == 3 ? p.bRays[curBatch] : p.rays;
                 const float4 *in = reinterpret_cast<const float4 *>(batchRays) + 2 * (long)newRi;
@@ -369,7 +378,7 @@ void trace_kernel(TraceParams p) {
                     cold[kColdTime][lane] = r1.w;  // ray.time: read by animated instances
                     floor = -1;
                 }
-                if (p.hasHostPrims) cold[kColdHost][lane] = 0.0f;
+                if (!kLean && p.hasHostPrims) cold[kColdHost][lane] = 0.0f;
                 visited = 1;  // the root
                 tests = 0;
                 found = false;
@@ -388,7 +397,9 @@ void trace_kernel(TraceParams p) {
             // ---- primitive step: lanes with a pending leaf test ONE primitive -----------
             // (up to p.primRepeat of them per scheduling decision: lanes whose leaf is finished sit the
             // rest out, lanes still inside theirs go on without another round of ballots)
-            for (int prep = 0; prep < p.primRepeat; ++prep) {
+            // (the one-launch kernel keeps ONE: the loop costs it registers and 8 % of its rate)
+            const int nPrep = (MODE == 3) ? 1 : p.primRepeat;
+            for (int prep = 0; prep < nPrep; ++prep) {
             if (prep > 0 && __ballot(cur < 0 && cur != kDone) == 0ull) break;
             if (cur < 0 && cur != kDone) {
                 if (INST && cur == kReturn) leave_instance();
@@ -398,7 +409,7 @@ void trace_kernel(TraceParams p) {
                     const unsigned flags = __float_as_uint(s1.w);
                     if (INST && (flags & kPrimInstance)) {
                         enter_instance(slot, flags, s0, s1, s2);
-                    } else if (flags & kPrimHost) {
+                    } else if (!kLean && (flags & kPrimHost)) {
                         // a primitive only the host can intersect (quadric, curve, alpha-tested
                         // ...): this ray's result is void and the caller re-traces it on the CPU
                         cold[kColdHost][lane] = 1.0f;
@@ -450,7 +461,7 @@ void trace_kernel(TraceParams p) {
                         }
                         bool closestLane = MODE == 0;
                         if (MODE == 3 && hit)
-                            closestLane = !((p.anyMask >> (__float_as_int(cold[kColdRi][lane]) >> kFusedIndexBits)) & 1u);
+                            closestLane = !((p.anyMask >> ((kLean ? riReg : __float_as_int(cold[kColdRi][lane])) >> kFusedIndexBits)) & 1u);
                         if (hit) {
                             if (closestLane) {
                                 cold[kColdHit][lane] = s0.w;  // primitive id bits
@@ -574,7 +585,7 @@ static hipError_t launch_fused(const TraceParams &p, int window, int instanced, 
                                hipStream_t stream, int *occupancy) {
     if (window != 8 || (patches & 2)) return hipErrorInvalidValue;
     if (instanced) return launch_one<3, 8, 1, 1>(p, blocks, stream, occupancy);
-    if (!patches) return launch_one<3, 8, 0, 0>(p, blocks, stream, occupancy);
+    if (!patches && !p.hasHostPrims) return launch_one<3, 8, 0, 0>(p, blocks, stream, occupancy);
     return launch_one<3, 8, 0, 1>(p, blocks, stream, occupancy);
 }
 
@@ -585,7 +596,7 @@ static hipError_t launch_mode(const TraceParams &p, int window, int instanced, i
     if (patches & 2) return instanced ? launch_one<MODE, 8, 1, 1, 1>(p, blocks, stream, occupancy)
                                       : launch_one<MODE, 8, 0, 1, 1>(p, blocks, stream, occupancy);
     if (instanced) return launch_one<MODE, 8, 1, 1>(p, blocks, stream, occupancy);
-    if (!patches && window == 8) return launch_one<MODE, 8, 0, 0>(p, blocks, stream, occupancy);
+    if (!patches && !p.hasHostPrims && window == 8) return launch_one<MODE, 8, 0, 0>(p, blocks, stream, occupancy);
     switch (window) {
     case 4: return launch_one<MODE, 4, 0, 1>(p, blocks, stream, occupancy);
     case 8: return launch_one<MODE, 8, 0, 1>(p, blocks, stream, occupancy);
