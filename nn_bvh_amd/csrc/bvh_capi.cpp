@@ -127,6 +127,14 @@ static bool validate_tree(const nnbvh_linear_node *nodes, int root, int n_tree, 
         }
         max_depth = std::max(max_depth, f.depth);
         const nnbvh_linear_node &nd = nodes[f.node];
+        // Bounds3f with min <= max on every axis (and no NaN): what every builder emits, and what the
+        // interior step's form of the slab test (trace_math.h slab_entry_key) is equal to the
+        // reference's for
+        for (int k = 0; k < 3; ++k)
+            if (!(nd.pmin[k] <= nd.pmax[k])) {
+                set_error("scene_create: node bounds with min > max (or NaN)");
+                return false;
+            }
         if (nd.nprims > 0) {
             if (f.node + 1 != f.end) {
                 set_error("scene_create: leaf does not close its subtree range (not a DFS layout)");

@@ -66,7 +66,9 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 // The interior step keeps its box-test verdicts as 0 / 1 integers in VGPRs and pushes without a branch
 // (measured +0.6 .. 1.9 % per ray class and 8 VGPRs fewer than combining compare masks on the scalar
 // unit; -DNNBVH_SCALAR_LOGIC builds the earlier form for comparison)
-#ifndef NNBVH_SCALAR_LOGIC
+#if !defined(NNBVH_SCALAR_LOGIC) && !defined(NNBVH_BITS_LOGIC)
+#define NNBVH_KEY_LOGIC 1
+#elif defined(NNBVH_BITS_LOGIC)
 #define NNBVH_VALU_LOGIC 1
 #endif
 //
@@ -509,8 +511,32 @@ void trace_kernel(TraceParams p) {
                 const int axis = __float_as_int(q3.z);
                 // aggregates.cpp:562-568: near child = second child iff dirIsNeg[axis]
                 const bool swap = (axis == 0 ? r.inv.x : (axis == 1 ? r.inv.y : r.inv.z)) < 0.0f;
+#if defined(NNBVH_KEY_LOGIC)
+                // one float per child: its entry distance, +inf if the box is missed whatever tMax is
+                // (slab_entry_key) — the verdicts are then two compares against tMax
+                const float k0 = slab_entry_key(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r);
+                const float k1 = slab_entry_key(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r);
+                const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
+                const float nearT = swap ? k1 : k0, farT = swap ? k0 : k1;
+                const bool nearE = true;
+                visited += 1;  // the near child is entered now
+                // a far child that fails against today's tMax would fail when popped (tMax only shrinks):
+                // it is counted now and never pushed.  MODE 1 pushes it all the same (exact counts up to
+                // the first hit).
+                const bool doPush = (MODE == 1) || (farT < tMax);
+                if (doPush && sp - base == W - 1) {
+                    uint2 e;
+                    e.x = (unsigned)sref[base & (W - 1)][lane];
+                    e.y = __float_as_uint(skey[base & (W - 1)][lane]);
+                    p.spill[(long)base * spillStride + gtid] = e;
+                    ++base;
+                }
+                sref[sp & (W - 1)][lane] = farRef;
+                skey[sp & (W - 1)][lane] = farT;
+                sp += doPush ? 1 : 0;
+                if (MODE == 0 || MODE == 3) visited += doPush ? 0 : 1;
+#elif defined(NNBVH_VALU_LOGIC)
                 float t0, t1;
-#ifdef NNBVH_VALU_LOGIC
                 // verdicts as 0 / 1 integers in VGPRs and a push without a branch: the scalar unit, which
                 // this kernel keeps busier than the vector ALUs, drops out of the step's boolean algebra
                 const unsigned b0 = slab_partial_bits(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, t0);
@@ -535,6 +561,7 @@ void trace_kernel(TraceParams p) {
                 sp += doPush ? 1 : 0;
                 if (MODE == 0 || MODE == 3) visited += doPush ? 0 : 1;  // popped and rejected later: same count
 #else
+                float t0, t1;
                 const bool e0 = slab_partial(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, t0);
                 const bool e1 = slab_partial(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, t1);
                 const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;

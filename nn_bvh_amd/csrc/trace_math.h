@@ -130,6 +130,39 @@ DEV unsigned slab_partial_bits(float mnx, float mny, float mnz, float mxx, float
     return ok & as_bit(tMax > 0.0f);
 }
 
+// The same test reduced to ONE float per box: the entry distance if every test of the reference
+// other than `tMin < raytMax` passes, +inf otherwise — so that `key < raytMax` IS the reference's
+// verdict, now for the near child and later (against the then-current tMax) for a far child.
+//
+// With a_k / b_k the per-axis entry / widened exit distances (k = x, y, z) the reference rejects iff
+// a_x > b_y, a_y > b_x (first early-out), max'(a_x, a_y) > b_z or a_z > min'(b_x, b_y) (second), i.e.
+// iff a_i > b_j for some i != j, where max' / min' keep their first operand when the other is NaN;
+// it accepts iff additionally max'(a) < raytMax and min'(b) > 0.  Three facts make that equal to
+// `x ordered  &&  max'(a) <= min'(b)  &&  min'(b) > 0  &&  max'(a) < raytMax`:
+//  * a NaN a_x or b_x always ends in a miss (every comparison it enters is false, and it survives
+//    into the final tMin / tMax), while a NaN in y or z is ignored by both forms: v_max_f32 /
+//    v_min_f32 return the other operand, as the reference's `if (ty > t) t = ty` does;
+//  * the only pairs the second form adds are the diagonal ones, a_k > b_k.  For a box with
+//    min <= max (checked when the scene is created) rounding is monotone, so a_k <= the unwidened
+//    exit distance; widening by 1 + 2 gamma(3) only moves b_k below a_k when b_k < 0, and then
+//    min'(b) > 0 fails in both forms;
+//  * max' and v_max_f32 may differ in the sign of a zero, which no comparison sees.
+// tools/slab_equivalence (tests/test_slab_equivalence.py) checks the two forms against each other on
+// adversarial boxes and rays (zero / infinite / NaN components, origins on slab planes).
+DEV float slab_entry_key(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const RayState &r) {
+    constexpr float widen = 1.0f + 2.0f * gamma_f(3);
+    const float ax = (((r.inv.x < 0.0f) ? mxx : mnx) - r.o.x) * r.inv.x;
+    const float bx = ((((r.inv.x < 0.0f) ? mnx : mxx) - r.o.x) * r.inv.x) * widen;
+    const float ay = (((r.inv.y < 0.0f) ? mxy : mny) - r.o.y) * r.inv.y;
+    const float by = ((((r.inv.y < 0.0f) ? mny : mxy) - r.o.y) * r.inv.y) * widen;
+    const float az = (((r.inv.z < 0.0f) ? mxz : mnz) - r.o.z) * r.inv.z;
+    const float bz = ((((r.inv.z < 0.0f) ? mnz : mxz) - r.o.z) * r.inv.z) * widen;
+    const float a = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
+    const float b = __builtin_fminf(__builtin_fminf(bx, by), bz);
+    const bool ok = !__builtin_isunordered(ax, bx) & (a <= b) & (b > 0.0f);
+    return ok ? a : __builtin_inff();
+}
+
 // shapes.cpp:172-273.  `degenerate` is the reference's first test
 // (LengthSquared(Cross(p2 - p0, p1 - p0)) == 0, :176-177): it depends on the triangle only and
 // is evaluated once, with the same float32 operations, when the scene is baked (kPrimDegenerate).

@@ -148,6 +148,10 @@ def test_scene_create_validates_tree_and_fails_loudly_without_gpu(nnbvh_lib):
     bad = tree.nodes.copy()
     bad["axis"][interior[0]] = 7
     assert not create(bad) and "axis" in _lib.last_error()
+    for value in (np.float32(np.nan), None):  # NaN, or min > max on one axis: not a Bounds3f a builder emits
+        bad = tree.nodes.copy()
+        bad["pmin"][interior[-1], 1] = value if value is not None else bad["pmax"][interior[-1], 1] + 1
+        assert not create(bad) and "min > max" in _lib.last_error()
     badp = tree.ordered_prims.copy()
     badp["kind"][0] = 9
     assert not create(tree.nodes, badp) and "kind" in _lib.last_error()
