@@ -407,7 +407,12 @@ void trace_kernel(TraceParams p) {
                 if (INST && cur == kReturn) leave_instance();
                 if (cur < 0 && cur != kDone && cur != kReturn) {
                     const int slot = ~cur;
-                    const float4 s0 = p.prims[slot], s1 = p.prims[slot + 1], s2 = p.prims[slot + 2];
+                    float4 s0 = p.prims[slot], s1 = p.prims[slot + 1], s2 = p.prims[slot + 2];
+                    // all three slots are fetched before anything looks at the flags: left alone the compiler
+                    // loads the flag word first and the vertices only inside the not-degenerate branch, two
+                    // dependent trips to memory per primitive
+                    asm volatile("" : "+v"(s0.x), "+v"(s0.y), "+v"(s0.z), "+v"(s0.w), "+v"(s1.x), "+v"(s1.y),
+                                      "+v"(s1.z), "+v"(s1.w), "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(s2.w));
                     const unsigned flags = __float_as_uint(s1.w);
                     if (INST && (flags & kPrimInstance)) {
                         enter_instance(slot, flags, s0, s1, s2);

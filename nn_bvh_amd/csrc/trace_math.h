@@ -26,6 +26,9 @@ DEV float dop(float a, float b, float c, float d) {
     return diff + err;
 }
 
+DEV float fmax3(float a, float b, float c) {  // v_max3_f32: a NaN operand is ignored
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
+}
 DEV float max3(float a, float b, float c) {  // std::max({a,b,c})
     float m = a;
     if (m < b) m = b;
@@ -210,17 +213,22 @@ DEV bool triangle_test(const RayState &r, float tMax, bool degenerate, V3 p0, V3
     else if (det > 0 && (tScaled <= 0 || tScaled > tMax * det)) return false;
     float invDet = 1.0f / det;
     float t = tScaled * invDet;
-    float maxZt = max3(__builtin_fabsf(p0z), __builtin_fabsf(p1z), __builtin_fabsf(p2z));
+    // std::max({a, b, c}) (vecmath.h:448-451) is NaN iff its FIRST element is (every later
+    // `largest < x` is then false) and ignores a NaN second or third element; v_max3_f32 ignores a NaN
+    // anywhere.  The four maxima reach nothing but deltaT, which a NaN maximum turns into NaN, and
+    // `t <= NaN` is false: one flag over the four first elements restores the difference.
+    const bool firstIsNan = __builtin_isunordered(p0z, p0x) | __builtin_isunordered(p0y, e0);
+    float maxZt = fmax3(__builtin_fabsf(p0z), __builtin_fabsf(p1z), __builtin_fabsf(p2z));
     float deltaZ = gamma_f(3) * maxZt;
-    float maxXt = max3(__builtin_fabsf(p0x), __builtin_fabsf(p1x), __builtin_fabsf(p2x));
-    float maxYt = max3(__builtin_fabsf(p0y), __builtin_fabsf(p1y), __builtin_fabsf(p2y));
+    float maxXt = fmax3(__builtin_fabsf(p0x), __builtin_fabsf(p1x), __builtin_fabsf(p2x));
+    float maxYt = fmax3(__builtin_fabsf(p0y), __builtin_fabsf(p1y), __builtin_fabsf(p2y));
     float deltaX = gamma_f(5) * (maxXt + maxZt);
     float deltaY = gamma_f(5) * (maxYt + maxZt);
     float deltaE = 2.0f * (gamma_f(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
-    float maxE = max3(__builtin_fabsf(e0), __builtin_fabsf(e1), __builtin_fabsf(e2));
+    float maxE = fmax3(__builtin_fabsf(e0), __builtin_fabsf(e1), __builtin_fabsf(e2));
     float deltaT = 3.0f * (gamma_f(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) *
                    __builtin_fabsf(invDet);
-    if (t <= deltaT) return false;
+    if (!firstIsNan & (t <= deltaT)) return false;
     b0 = e0 * invDet;
     b1 = e1 * invDet;
     b2 = e2 * invDet;
