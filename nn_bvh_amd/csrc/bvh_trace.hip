@@ -153,25 +153,37 @@ void trace_kernel(TraceParams p) {
     bool exhausted = false;
 
     // pop entries until one whose deferred box test passes with the current tMax
+    auto pop_entry = [&](int &ref, float &key) {
+        --sp;
+        ref = sref[sp & (W - 1)][lane];  // always an LDS read (stale if spilled)
+        key = skey[sp & (W - 1)][lane];
+        asm volatile("" : "+v"(ref), "+v"(key));  // keeps the two reads ds_read (no flat select)
+        if (sp < base) {                     // rare: the entry lives in the HBM spill array
+            const uint2 e = p.spill[(long)sp * spillStride + gtid];
+            base = sp;
+            ref = (int)e.x;
+            key = __uint_as_float(e.y);
+            // complete the load inside this rare branch, so that the common path's join
+            // needs no vmcnt wait
+            asm volatile("" : "+v"(ref), "+v"(key));
+        }
+        if (MODE != 2) visited += 1;
+    };
     auto pop_next = [&]() -> int {
-        while (sp > ((INST && floor > 0) ? floor : 0)) {
-            --sp;
-            int ref = sref[sp & (W - 1)][lane];  // always an LDS read (stale if spilled)
-            float key = skey[sp & (W - 1)][lane];
-            asm volatile("" : "+v"(ref), "+v"(key));  // keeps the two reads ds_read (no flat select)
-            if (sp < base) {                     // rare: the entry lives in the HBM spill array
-                const uint2 e = p.spill[(long)sp * spillStride + gtid];
-                base = sp;
-                ref = (int)e.x;
-                key = __uint_as_float(e.y);
-                // complete the load inside this rare branch, so that the common path's join
-                // needs no vmcnt wait
-                asm volatile("" : "+v"(ref), "+v"(key));
-            }
-            if (MODE != 2) visited += 1;
+        const int lowest = (INST && floor > 0) ? floor : 0;
+        const int none = (INST && floor >= 0) ? kReturn : kDone;
+        if (sp <= lowest) return none;
+        // the first entry is nearly always the one: a child that failed against tMax when its parent
+        // was visited was never pushed, so only a tMax that shrank since then rejects an entry here
+        int ref;
+        float key;
+        pop_entry(ref, key);
+        if (key < tMax) return ref;
+        while (sp > lowest) {
+            pop_entry(ref, key);
             if (key < tMax) return ref;
         }
-        return (INST && floor >= 0) ? kReturn : kDone;
+        return none;
     };
 
     // TransformedPrimitive::Intersect / IntersectP (cpu/primitive.cpp:112-131): park the outer ray
@@ -494,13 +506,13 @@ void trace_kernel(TraceParams p) {
         } else {
             // ---- interior step(s): up to p.intRepeat in a row before the next scheduling
             // decision (lanes that leave the interior state sit the remaining ones out) -------
-            for (int rep = 0; rep < p.intRepeat; ++rep) {
-                if (rep > 0 && __ballot(cur >= 0) == 0ull) break;
+            int rep = 0;
+            do {
 #ifdef NNBVH_STATS
                 st[14] += 1;
                 st[15] += __popcll(__ballot(cur >= 0));
 #endif
-                if (cur < 0) continue;
+                if (cur >= 0) {
 #ifdef NNBVH_PROBE_SALU  // sensitivity probes (tools only): extra scalar / vector instructions per interior step
 #pragma unroll
                 for (int k = 0; k < NNBVH_PROBE_SALU; ++k) asm volatile("s_add_u32 s95, s95, 1" ::: "s95", "scc");
@@ -591,7 +603,8 @@ void trace_kernel(TraceParams p) {
 #endif
                 if (nearE && nearT < tMax) cur = nearRef;
                 else cur = pop_next();
-            }
+                }
+            } while (++rep < p.intRepeat && __ballot(cur >= 0) != 0ull);
         }
     }
 #ifdef NNBVH_STATS
