@@ -60,6 +60,9 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 #ifndef NNBVH_MINW_ANY
 #define NNBVH_MINW_ANY 6
 #endif
+#ifndef NNBVH_FUSED_PRIM_LOOP
+#define NNBVH_FUSED_PRIM_LOOP 0
+#endif
 #ifndef NNBVH_LEAN_EXTRA_WAVES
 #define NNBVH_LEAN_EXTRA_WAVES 2
 #endif
@@ -412,9 +415,9 @@ void trace_kernel(TraceParams p) {
             // (up to p.primRepeat of them per scheduling decision: lanes whose leaf is finished sit the
             // rest out, lanes still inside theirs go on without another round of ballots)
             // (the one-launch kernel keeps ONE: the loop costs it registers and 8 % of its rate)
-            const int nPrep = (MODE == 3) ? 1 : p.primRepeat;
-            for (int prep = 0; prep < nPrep; ++prep) {
-            if (prep > 0 && __ballot(cur < 0 && cur != kDone) == 0ull) break;
+            const int nPrep = (MODE == 3 && !NNBVH_FUSED_PRIM_LOOP) ? 1 : p.primRepeat;
+            int prep = 0;
+            do {
             if (cur < 0 && cur != kDone) {
                 if (INST && cur == kReturn) leave_instance();
                 if (cur < 0 && cur != kDone && cur != kReturn) {
@@ -502,7 +505,7 @@ void trace_kernel(TraceParams p) {
                     }
                 }
             }
-            }
+            } while (++prep < nPrep && __ballot(cur < 0 && cur != kDone) != 0ull);
         } else {
             // ---- interior step(s): up to p.intRepeat in a row before the next scheduling
             // decision (lanes that leave the interior state sit the remaining ones out) -------
