@@ -91,8 +91,9 @@ __global__ __launch_bounds__(kBlockThreads, (INST ? 1 : ((MODE == 0 || MODE == 3
 void trace_kernel(TraceParams p) {
     static_assert(PATCH || !INST, "two-level scenes need the ray direction");
     static_assert(PATCH || !ALPHA, "the alpha test hashes the ray direction");
-    __shared__ int s_ref[kBlockThreads / 64][W][64];
-    __shared__ float s_key[kBlockThreads / 64][W][64];
+    // the stack window: entry k of a lane = (child reference, entry distance), the two words 64 dwords
+    // apart so that one ds_read2st64 / ds_write2st64 with one address moves both
+    __shared__ float s_stack[kBlockThreads / 64][W][2][64];
     // Cold per-ray state parked in LDS ([field][lane], conflict-free) instead of VGPRs: the
     // ray index (read when the ray retires), the direction (read by the patch test only; the
     // triangle test uses the precomputed shear) and, closest hit, the current best hit
@@ -116,8 +117,7 @@ void trace_kernel(TraceParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int gtid = blockIdx.x * kBlockThreads + threadIdx.x;
-    int(*sref)[64] = s_ref[wave];
-    float(*skey)[64] = s_key[wave];
+    float(*stk)[2][64] = s_stack[wave];
     float(*cold)[64] = s_cold[wave];
     int riReg = -1;  // lean instances: the ray this lane carries, -1 = none
     if (!kLean) cold[kColdRi][lane] = __int_as_float(-1);
@@ -158,8 +158,8 @@ void trace_kernel(TraceParams p) {
     // pop entries until one whose deferred box test passes with the current tMax
     auto pop_entry = [&](int &ref, float &key) {
         --sp;
-        ref = sref[sp & (W - 1)][lane];  // always an LDS read (stale if spilled)
-        key = skey[sp & (W - 1)][lane];
+        ref = __float_as_int(stk[sp & (W - 1)][0][lane]);  // always an LDS read (stale if spilled)
+        key = stk[sp & (W - 1)][1][lane];
         asm volatile("" : "+v"(ref), "+v"(key));  // keeps the two reads ds_read (no flat select)
         if (sp < base) {                     // rare: the entry lives in the HBM spill array
             const uint2 e = p.spill[(long)sp * spillStride + gtid];
@@ -530,7 +530,7 @@ void trace_kernel(TraceParams p) {
                 const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
                 const int axis = __float_as_int(q3.z);
                 // aggregates.cpp:562-568: near child = second child iff dirIsNeg[axis]
-                const bool swap = (axis == 0 ? r.inv.x : (axis == 1 ? r.inv.y : r.inv.z)) < 0.0f;
+                const bool swap = ((r.kz >> axis) & 1) != 0;  // dirIsNeg[axis], packed by ray_shear
 #if defined(NNBVH_KEY_LOGIC)
                 // one float per child: its entry distance, +inf if the box is missed whatever tMax is
                 // (slab_entry_key) — the verdicts are then two compares against tMax
@@ -546,13 +546,13 @@ void trace_kernel(TraceParams p) {
                 const bool doPush = (MODE == 1) || (farT < tMax);
                 if (doPush && sp - base == W - 1) {
                     uint2 e;
-                    e.x = (unsigned)sref[base & (W - 1)][lane];
-                    e.y = __float_as_uint(skey[base & (W - 1)][lane]);
+                    e.x = __float_as_uint(stk[base & (W - 1)][0][lane]);
+                    e.y = __float_as_uint(stk[base & (W - 1)][1][lane]);
                     p.spill[(long)base * spillStride + gtid] = e;
                     ++base;
                 }
-                sref[sp & (W - 1)][lane] = farRef;
-                skey[sp & (W - 1)][lane] = farT;
+                stk[sp & (W - 1)][0][lane] = __int_as_float(farRef);
+                stk[sp & (W - 1)][1][lane] = farT;
                 sp += doPush ? 1 : 0;
                 if (MODE == 0 || MODE == 3) visited += doPush ? 0 : 1;
 #elif defined(NNBVH_VALU_LOGIC)
@@ -571,13 +571,13 @@ void trace_kernel(TraceParams p) {
                 // be written there unconditionally; it only counts if sp moves past it
                 if (doPush && sp - base == W - 1) {
                     uint2 e;
-                    e.x = (unsigned)sref[base & (W - 1)][lane];
-                    e.y = __float_as_uint(skey[base & (W - 1)][lane]);
+                    e.x = __float_as_uint(stk[base & (W - 1)][0][lane]);
+                    e.y = __float_as_uint(stk[base & (W - 1)][1][lane]);
                     p.spill[(long)base * spillStride + gtid] = e;
                     ++base;
                 }
-                sref[sp & (W - 1)][lane] = farRef;
-                skey[sp & (W - 1)][lane] = farE ? farT : __builtin_inff();
+                stk[sp & (W - 1)][0][lane] = __int_as_float(farRef);
+                stk[sp & (W - 1)][1][lane] = farE ? farT : __builtin_inff();
                 sp += doPush ? 1 : 0;
                 if (MODE == 0 || MODE == 3) visited += doPush ? 0 : 1;  // popped and rejected later: same count
 #else
@@ -592,13 +592,13 @@ void trace_kernel(TraceParams p) {
                     // push far child with its entry distance (+inf: box already missed)
                     if (sp - base == W) {
                         uint2 e;
-                        e.x = (unsigned)sref[base & (W - 1)][lane];
-                        e.y = __float_as_uint(skey[base & (W - 1)][lane]);
+                        e.x = __float_as_uint(stk[base & (W - 1)][0][lane]);
+                        e.y = __float_as_uint(stk[base & (W - 1)][1][lane]);
                         p.spill[(long)base * spillStride + gtid] = e;
                         ++base;
                     }
-                    sref[sp & (W - 1)][lane] = farRef;
-                    skey[sp & (W - 1)][lane] = farE ? farT : __builtin_inff();
+                    stk[sp & (W - 1)][0][lane] = __int_as_float(farRef);
+                    stk[sp & (W - 1)][1][lane] = farE ? farT : __builtin_inff();
                     ++sp;
                 } else if (MODE == 0 || MODE == 3) {
                     visited += 1;  // the reference pops and rejects it later: same count

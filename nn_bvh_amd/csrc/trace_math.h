@@ -55,7 +55,7 @@ struct RayState {
     // permutation (kz = largest |d| component) and the shear Sx, Sy, Sz.  The reference
     // recomputes them for every triangle; computed once per ray they are the same floats.
     float sx, sy, sz;
-    int kz;
+    int kz;  // kz << 8 | dirIsNeg bits (bit k = inv.k < 0, aggregates.cpp:535): see ray_shear
 };
 
 DEV void ray_shear(RayState &r, V3 d) {
@@ -71,7 +71,9 @@ DEV void ray_shear(RayState &r, V3 d) {
     r.sx = -dx / dz;
     r.sy = -dy / dz;
     r.sz = 1.0f / dz;
-    r.kz = kz;
+    // r.inv is set by now: the three dirIsNeg flags ride in the low bits, for the interior step's
+    // `dirIsNeg[node->axis]` (one v_bfe_u32)
+    r.kz = (kz << 8) | (r.inv.x < 0.0f ? 1 : 0) | (r.inv.y < 0.0f ? 2 : 0) | (r.inv.z < 0.0f ? 4 : 0);
 }
 
 // Slab test of util/vecmath.h:1573-1608 split in two: everything that does not involve
@@ -173,7 +175,7 @@ DEV bool triangle_test(const RayState &r, float tMax, bool degenerate, V3 p0, V3
                        float &b0, float &b1, float &b2, float &tHit) {
     if (degenerate) return false;
     V3 a = sub(p0, r.o), b = sub(p1, r.o), c = sub(p2, r.o);
-    const int kz = r.kz;
+    const int kz = r.kz >> 8;
     int kx = kz + 1;
     if (kx == 3) kx = 0;
     int ky = kx + 1;
