@@ -31,7 +31,9 @@
 namespace nnbvh {
 
 constexpr int kKdBlock = 256;
-constexpr int kKdW = 8;              // LDS window of the to-visit stack, entries per lane
+constexpr int kKdW = 8;              // LDS window of the to-visit stack, entries per lane (patch instances)
+constexpr int kKdWLean = 4;          // ... of the lean instances: 18 KiB of LDS per block, 8 blocks per CU (measured
+                                     // against 8 entries / 5 blocks: crown +8 %, bathroom +11 %)
 constexpr int kKdQueues = 8;         // one ray queue per XCD
 constexpr int kKdQueueStride = 32;   // words: every queue head on its own 128-B line
 constexpr int kKdDone = -1;          // lane carries no ray
@@ -80,21 +82,22 @@ DEV bool kd_root_interval(const float bmin[3], const float bmax[3], V3 o, V3 inv
     return true;
 }
 
-// MODE 0: closest hit; MODE 1: any hit (counts written when asked for)
-template <int MODE>
-__global__ __launch_bounds__(kKdBlock) void kd_trace_kernel(KdParams p) {
-    __shared__ int s_node[kKdBlock / 64][kKdW][64];
-    __shared__ float s_tmin[kKdBlock / 64][kKdW][64];
-    __shared__ float s_tmax[kKdBlock / 64][kKdW][64];
+// MODE 0: closest hit; MODE 1: any hit (counts written when asked for).
+// PATCH = 0: the scene holds no bilinear patches — nothing reads the ray direction after the ray is
+// fetched except `ray.d[axis] <= 0` at interior nodes, which rides as three bits beside the shear's
+// kz; the patch test, the largest register consumer, is not compiled in.
+// W: entries per lane of the LDS window of the to-visit stack.
+template <int MODE, int PATCH, int W>
+__global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdParams p) {
+    // KdNodeToVisit {node, tMin, tMax}: the three words of an entry 64 dwords apart
+    __shared__ float s_stack[kKdBlock / 64][W][3][64];
     // cold per-ray state ([field][lane]): ray index, best hit (closest), reached-a-host-primitive flag
     constexpr int kColdRi = 0, kColdHit = 1, kColdHost = (MODE == 0) ? 5 : 1, kColdFields = kColdHost + 1;
     __shared__ float s_cold[kKdBlock / 64][kColdFields][64];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gtid = blockIdx.x * kKdBlock + threadIdx.x;
-    int(*snode)[64] = s_node[wave];
-    float(*stmin)[64] = s_tmin[wave];
-    float(*stmax)[64] = s_tmax[wave];
+    float(*stk)[3][64] = s_stack[wave];
     float(*cold)[64] = s_cold[wave];
     cold[kColdRi][lane] = __int_as_float(-1);
     const long spillStride = (long)gridDim.x * kKdBlock;
@@ -108,30 +111,32 @@ __global__ __launch_bounds__(kKdBlock) void kd_trace_kernel(KdParams p) {
     int queuesTried = 0;
     const long nRays = p.n;
 
-    RayState r;          // o, 1/d, shear
-    V3 d = {0, 0, 0};    // aggregates.cpp:1002-1003 reads ray.d[axis] at every interior node
+    RayState r;          // o, 1/d, shear; r.kz also carries bit 4 + k = (d[k] <= 0), see the refill
+    V3 d = {0, 0, 0};    // PATCH only: the patch test reads the direction
     float rayTMax = 0.0f, tMin = 0.0f, tMax = 0.0f;
     int visited = 0, tests = 0;
     int cur = kKdDone, sp = 0, base = 0;
-    int leafPos = 0, leafLeft = 0;
+    // a lane inside a leaf (cur == kKdLeaf): leafIdx = the primitive to test next, leafPos = where the
+    // index after it sits in primitiveIndices, leafLeft = primitives still to test including leafIdx
+    int leafIdx = 0, leafPos = 0, leafLeft = 0;
     bool found = false, exhausted = false;
 
     // aggregates.cpp:1053-1060 / :1098-1105: next entry of the to-visit list, or the ray is finished
     auto pop_or_done = [&]() {
         if (sp > 0) {
             --sp;
-            int node = snode[sp & (kKdW - 1)][lane];
-            float a = stmin[sp & (kKdW - 1)][lane], b = stmax[sp & (kKdW - 1)][lane];
+            float node = stk[sp & (W - 1)][0][lane];
+            float a = stk[sp & (W - 1)][1][lane], b = stk[sp & (W - 1)][2][lane];
             asm volatile("" : "+v"(node), "+v"(a), "+v"(b));
             if (sp < base) {  // rare: the entry lives in the HBM spill array
                 const float4 e = p.spill[(long)sp * spillStride + gtid];
                 base = sp;
-                node = __float_as_int(e.x);
+                node = e.x;
                 a = e.y;
                 b = e.z;
                 asm volatile("" : "+v"(node), "+v"(a), "+v"(b));
             }
-            cur = node;
+            cur = __float_as_int(node);
             tMin = a;
             tMax = b;
         } else {
@@ -199,9 +204,12 @@ __global__ __launch_bounds__(kKdBlock) void kd_trace_kernel(KdParams p) {
                 const float4 r0 = in[0], r1 = in[1];
                 r.o = {r0.x, r0.y, r0.z};
                 rayTMax = r0.w;
-                d = {r1.x, r1.y, r1.z};
-                r.inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};  // aggregates.cpp:980
-                ray_shear(r, d);
+                const V3 dir = {r1.x, r1.y, r1.z};
+                if (PATCH) d = dir;
+                r.inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};  // aggregates.cpp:980
+                ray_shear(r, dir);
+                // `ray.d[axis] <= 0` of aggregates.cpp:1002-1003, once per ray
+                r.kz |= (dir.x <= 0.0f ? 16 : 0) | (dir.y <= 0.0f ? 32 : 0) | (dir.z <= 0.0f ? 64 : 0);
                 if (MODE == 0) {
                     cold[kColdHit][lane] = __int_as_float(-1);
                     cold[kColdHit + 1][lane] = 0.0f;
@@ -222,9 +230,14 @@ __global__ __launch_bounds__(kKdBlock) void kd_trace_kernel(KdParams p) {
         if (sP > sI || nNode == 0) {
             // ---- primitive step: lanes inside a leaf test ONE primitive ------------------------
             if (cur == kKdLeaf) {
-                const int index = leafPos < 0 ? ~leafPos : p.primIndices[leafPos];
-                const float4 *rec = p.prims + 4 * (long)index;
-                const float4 s0 = rec[0], s1 = rec[1], s2 = rec[2];
+                // one trip to memory: the primitive's three slots and — if the leaf goes on — the index of
+                // the primitive after it, all issued before anything is looked at
+                const float4 *rec = p.prims + 4 * (long)leafIdx;
+                float4 s0 = rec[0], s1 = rec[1], s2 = rec[2];
+                int nextIdx = 0;
+                if (leafLeft > 1) nextIdx = p.primIndices[leafPos];
+                asm volatile("" : "+v"(s0.x), "+v"(s0.y), "+v"(s0.z), "+v"(s0.w), "+v"(s1.x), "+v"(s1.y),
+                                  "+v"(s1.z), "+v"(s1.w), "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(nextIdx));
                 const unsigned flags = __float_as_uint(s1.w);
                 if (flags & kPrimHost) {
                     cold[kColdHost][lane] = 1.0f;
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(kKdBlock) void kd_trace_kernel(KdParams p) {
                     tests += 1;
                     bool hit;
                     float x0, x1, x2, th;
-                    if (!(flags & kPrimPatch)) {
+                    if (!PATCH || !(flags & kPrimPatch)) {
                         hit = triangle_test(r, rayTMax, (flags & kPrimDegenerate) != 0, {s0.x, s0.y, s0.z},
                                             {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z}, x0, x1, x2, th);
                     } else {
@@ -254,67 +267,72 @@ __global__ __launch_bounds__(kKdBlock) void kd_trace_kernel(KdParams p) {
                     }
                 }
                 leafLeft -= 1;
-                if (leafPos >= 0) leafPos += 1;
+                leafIdx = nextIdx;
+                leafPos += 1;
                 if (MODE == 1 && found) cur = kKdDone;  // :1091-1094, :1101-1104
                 else if (leafLeft == 0) pop_or_done();
             }
         } else {
-            // ---- node step(s) --------------------------------------------------------------------
-            for (int rep = 0; rep < p.nodeRepeat; ++rep) {
-                if (rep > 0 && __ballot(cur >= 0) == 0ull) break;
-                if (cur < 0) continue;
-                if (MODE == 0 && rayTMax < tMin) {  // :989-991 a hit closer than this node: finished
-                    cur = kKdDone;
-                    continue;
-                }
-                visited += 1;
-                const uint2 nd = p.nodes[cur];
-                const unsigned flags = nd.y;
-                if ((flags & 3u) != 3u) {
-                    // interior (:993-1023 / :1110-1144)
-                    const int axis = (int)(flags & 3u);
-                    const float split = __uint_as_float(nd.x);
-                    const float oa = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
-                    const float ia = axis == 0 ? r.inv.x : (axis == 1 ? r.inv.y : r.inv.z);
-                    const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-                    const float tSplit = (split - oa) * ia;
-                    const bool belowFirst = (oa < split) || (oa == split && da <= 0.0f);
-                    const int above = (int)(flags >> 2);
-                    const int firstChild = belowFirst ? cur + 1 : above;
-                    const int secondChild = belowFirst ? above : cur + 1;
-                    if (tSplit > tMax || tSplit <= 0.0f) {
-                        cur = firstChild;
-                    } else if (tSplit < tMin) {
-                        cur = secondChild;
+            // ---- node step(s): up to p.nodeRepeat in a row before the next scheduling decision ------
+            int rep = 0;
+            do {
+                if (cur >= 0) {
+                    if (MODE == 0 && rayTMax < tMin) {  // :989-991 a hit closer than this node: finished
+                        cur = kKdDone;
                     } else {
-                        if (sp - base == kKdW) {  // window full: its oldest entry goes to HBM
-                            float4 e;
-                            e.x = __int_as_float(snode[base & (kKdW - 1)][lane]);
-                            e.y = stmin[base & (kKdW - 1)][lane];
-                            e.z = stmax[base & (kKdW - 1)][lane];
-                            e.w = 0.0f;
-                            p.spill[(long)base * spillStride + gtid] = e;
-                            ++base;
+                        visited += 1;
+                        const uint2 nd = p.nodes[cur];
+                        const unsigned flags = nd.y;
+                        if ((flags & 3u) != 3u) {
+                            // interior (:993-1023 / :1110-1144)
+                            const int axis = (int)(flags & 3u);
+                            const float split = __uint_as_float(nd.x);
+                            const float oa = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
+                            const float ia = axis == 0 ? r.inv.x : (axis == 1 ? r.inv.y : r.inv.z);
+                            const bool dLe0 = ((r.kz >> (4 + axis)) & 1) != 0;  // ray.d[axis] <= 0
+                            const float tSplit = (split - oa) * ia;
+                            const bool belowFirst = (oa < split) || (oa == split && dLe0);
+                            const int above = (int)(flags >> 2);
+                            const int firstChild = belowFirst ? cur + 1 : above;
+                            const int secondChild = belowFirst ? above : cur + 1;
+                            if (tSplit > tMax || tSplit <= 0.0f) {
+                                cur = firstChild;
+                            } else if (tSplit < tMin) {
+                                cur = secondChild;
+                            } else {
+                                if (sp - base == W) {  // window full: its oldest entry goes to HBM
+                                    float4 e;
+                                    e.x = stk[base & (W - 1)][0][lane];
+                                    e.y = stk[base & (W - 1)][1][lane];
+                                    e.z = stk[base & (W - 1)][2][lane];
+                                    e.w = 0.0f;
+                                    p.spill[(long)base * spillStride + gtid] = e;
+                                    ++base;
+                                }
+                                stk[sp & (W - 1)][0][lane] = __int_as_float(secondChild);
+                                stk[sp & (W - 1)][1][lane] = tSplit;
+                                stk[sp & (W - 1)][2][lane] = tMax;
+                                ++sp;
+                                cur = firstChild;
+                                tMax = tSplit;
+                            }
+                        } else {
+                            // leaf (:1025-1061 / :1084-1107): one primitive index lives in the node itself,
+                            // several sit in primitiveIndices — the first of them is fetched here, so that
+                            // every primitive step is ONE trip to memory
+                            const int nPrimitives = (int)(flags >> 2);
+                            if (nPrimitives == 0) {
+                                pop_or_done();
+                            } else {
+                                leafLeft = nPrimitives;
+                                leafPos = (int)nd.x + 1;
+                                leafIdx = nPrimitives == 1 ? (int)nd.x : p.primIndices[(int)nd.x];
+                                cur = kKdLeaf;
+                            }
                         }
-                        snode[sp & (kKdW - 1)][lane] = secondChild;
-                        stmin[sp & (kKdW - 1)][lane] = tSplit;
-                        stmax[sp & (kKdW - 1)][lane] = tMax;
-                        ++sp;
-                        cur = firstChild;
-                        tMax = tSplit;
-                    }
-                } else {
-                    // leaf (:1025-1061 / :1084-1107): one primitive index lives in the node itself
-                    const int nPrimitives = (int)(flags >> 2);
-                    if (nPrimitives == 0) {
-                        pop_or_done();
-                    } else {
-                        leafLeft = nPrimitives;
-                        leafPos = nPrimitives == 1 ? ~(int)nd.x : (int)nd.x;
-                        cur = kKdLeaf;
                     }
                 }
-            }
+            } while (++rep < p.nodeRepeat && __ballot(cur >= 0) != 0ull);
         }
     }
 }
@@ -383,6 +401,7 @@ struct nnbvh_kd_scene {
     int n_cus = 0;
     int depth = 0;
     int has_host_prims = 0;
+    int has_patches = 0;
     float bounds[6];
     uint2 *d_nodes = nullptr;
     int32_t *d_indices = nullptr;
@@ -427,20 +446,20 @@ static int kd_launch(nnbvh_kd_scene *s, int mode, const void *d_rays, int64_t n,
     p.nodeRepeat = 4;
     p.hasHostPrims = s->has_host_prims;
     p.spill = w->spill;
+    // the four instances: closest / any hit x scenes with / without bilinear patches
+    void (*const kernels[4])(KdParams) = {kd_trace_kernel<0, 0, kKdWLean>, kd_trace_kernel<1, 0, kKdWLean>,
+                                          kd_trace_kernel<0, 1, kKdW>, kd_trace_kernel<1, 1, kKdW>};
+    void (*const kernel)(KdParams) = kernels[mode + 2 * s->has_patches];
     if (s->blocks_per_cu[mode] == 0) {
         int occ = 0;
-        const hipError_t e = mode == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kd_trace_kernel<0>, kKdBlock, 0)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kd_trace_kernel<1>, kKdBlock, 0);
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kKdBlock, 0);
         s->blocks_per_cu[mode] = (e == hipSuccess && occ > 0) ? std::min(occ, 8) : 4;
     }
     int blocks = s->n_cus * s->blocks_per_cu[mode];
     const int64_t need = (n + kKdBlock - 1) / kKdBlock;
     if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
     hipLaunchKernelGGL(kd_zero_queue_kernel, dim3(1), dim3(256), 0, stream, w->queue, kKdQueues * kKdQueueStride);
-    if (mode == 0)
-        hipLaunchKernelGGL(kd_trace_kernel<0>, dim3((unsigned)blocks), dim3(kKdBlock), 0, stream, p);
-    else
-        hipLaunchKernelGGL(kd_trace_kernel<1>, dim3((unsigned)blocks), dim3(kKdBlock), 0, stream, p);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kKdBlock), 0, stream, p);
     return kd_hip_ok(hipGetLastError(), "kd trace kernel launch") ? NNBVH_OK : NNBVH_ERR_DEVICE;
 }
 
@@ -517,7 +536,7 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
     }
     // ---- primitive records: 4 slots per primitive in the caller's order --------------------------
     std::vector<float> rec((size_t)n_prims * 16, 0.0f);
-    bool has_host = false;
+    bool has_host = false, has_patch = false;
     for (int k = 0; k < n_prims; ++k) {
         const nnbvh_prim &pr = prims[k];
         float *s = &rec[(size_t)k * 16];
@@ -536,7 +555,10 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
                 std::memcpy(&s[4 * j], verts + 3 * (size_t)pr.v[j], 12);
             }
             std::memcpy(&s[3], &pr.id, 4);
-            if (nv == 4) flags |= kPrimPatch;
+            if (nv == 4) {
+                flags |= kPrimPatch;
+                has_patch = true;
+            }
             else if (kd_triangle_is_degenerate(&s[0], &s[4], &s[8])) flags |= kPrimDegenerate;
         } else {
             set_error("kd_scene_create: unsupported primitive kind (triangles, patches, host primitives)");
@@ -558,6 +580,7 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
     s->n_cus = prop.multiProcessorCount;
     s->depth = max_depth;
     s->has_host_prims = has_host ? 1 : 0;
+    s->has_patches = has_patch ? 1 : 0;
     std::memcpy(s->bounds, bounds_min_max, 24);
     const size_t ni = (size_t)std::max(n_indices, 1);
     bool ok = kd_hip_ok(hipMalloc((void **)&s->d_nodes, (size_t)n_nodes * 8), "hipMalloc(kd nodes)") &&
