@@ -176,8 +176,7 @@ void trace_kernel(TraceParams p) {
         const int lowest = (INST && floor > 0) ? floor : 0;
         const int none = (INST && floor >= 0) ? kReturn : kDone;
         if (sp <= lowest) return none;
-        // the first entry is nearly always the one: a child that failed against tMax when its parent
-        // was visited was never pushed, so only a tMax that shrank since then rejects an entry here
+        // the first entry is usually the one (only a tMax that shrank since the push rejects it)
         int ref;
         float key;
         pop_entry(ref, key);
@@ -540,10 +539,13 @@ void trace_kernel(TraceParams p) {
                 const float nearT = swap ? k1 : k0, farT = swap ? k0 : k1;
                 const bool nearE = true;
                 visited += 1;  // the near child is entered now
-                // a far child that fails against today's tMax would fail when popped (tMax only shrinks):
-                // it is counted now and never pushed.  MODE 1 pushes it all the same (exact counts up to
-                // the first hit).
-                const bool doPush = (MODE == 1) || (farT < tMax);
+                // A far child whose tMax-independent tests failed (key +inf) can never be entered: it is
+                // counted now and not pushed.  One that merely fails against TODAY's tMax must be pushed:
+                // tMax is not monotone — a hit accepted with tScaled <= tMax * det can round to a t one ulp
+                // ABOVE the old tMax (shapes.cpp:239-244; rays that meet a shared vertex at exactly tMax do
+                // it), and the reference tests the far child against that later value.  MODE 1 pushes every
+                // far child (exact counts up to the first hit).
+                const bool doPush = (MODE == 1) || (farT < __builtin_inff());
                 if (doPush && sp - base == W - 1) {
                     uint2 e;
                     e.x = __float_as_uint(stk[base & (W - 1)][0][lane]);
