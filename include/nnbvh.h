@@ -160,6 +160,11 @@ int nnbvh_build_depth(const nnbvh_build *b); /* edges root -> deepest leaf */
 void nnbvh_build_destroy(nnbvh_build *b);
 
 /* ---- device scene ------------------------------------------------------------------ */
+/* Uploads and bakes a flattened tree (the reference's LinearBVHNode[] in its DFS layout, first child
+ * at index + 1) with its leaf-ordered primitives.  Everything the kernels index with is validated
+ * here: a malformed tree is NULL + nnbvh_last_error(), never a device fault.  Node bounds must be
+ * Bounds3f with pmin <= pmax on every axis and no NaN (what every builder emits; the kernels' form of
+ * the slab test is equal to Bounds3::IntersectP, util/vecmath.h:1573-1608, for such boxes). */
 nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
                                 const nnbvh_prim *ordered_prims, int n_prims,
                                 const float *verts, int n_verts, int device);

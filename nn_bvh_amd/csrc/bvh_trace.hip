@@ -337,7 +337,11 @@ void trace_kernel(TraceParams p) {
             long start = 0;
             for (;;) {  // find a queue with work left (own XCD's first, then steal)
                 if (MODE == 3) nRays = p.bN[curBatch];
-                const long qBegin = nRays * q / p.nQueues, qEnd = nRays * (q + 1) / p.nQueues;
+                // p.nQueues is 1 or kMaxQueues = 8: the division of a long is a shift (the scalar unit has
+                // no 64-bit divide; the compiler's expansion was ~250 instructions per refill)
+                static_assert(kMaxQueues == 8, "queue ranges are computed with a shift by 3");
+                const int qShift = p.nQueues > 1 ? 3 : 0;
+                const long qBegin = (nRays * q) >> qShift, qEnd = (nRays * (q + 1)) >> qShift;
                 unsigned got = 0;
                 if (lane == 0)
                     got = atomicAdd(&p.queue[((MODE == 3 ? curBatch * p.nQueues : 0) + q) * kQueueStrideWords],

@@ -181,7 +181,9 @@ __global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdPar
             int newRi = -1;
             if (exhausted) break;  // only reached with every lane idle
             for (;;) {
-                const long qBegin = nRays * q / p.nQueues, qEnd = nRays * (q + 1) / p.nQueues;
+                static_assert(kKdQueues == 8, "queue ranges are computed with a shift by 3");
+                const int qShift = p.nQueues > 1 ? 3 : 0;  // nQueues is 1 or 8: a shift, not a 64-bit division
+                const long qBegin = (nRays * q) >> qShift, qEnd = (nRays * (q + 1)) >> qShift;
                 unsigned got = 0;
                 if (lane == 0) got = atomicAdd(&p.queue[q * kKdQueueStride], (unsigned)nIdle);
                 got = __builtin_amdgcn_readfirstlane(got);
