@@ -66,14 +66,6 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 #ifndef NNBVH_LEAN_EXTRA_WAVES
 #define NNBVH_LEAN_EXTRA_WAVES 2
 #endif
-// The interior step keeps its box-test verdicts as 0 / 1 integers in VGPRs and pushes without a branch
-// (measured +0.6 .. 1.9 % per ray class and 8 VGPRs fewer than combining compare masks on the scalar
-// unit; -DNNBVH_SCALAR_LOGIC builds the earlier form for comparison)
-#if !defined(NNBVH_SCALAR_LOGIC) && !defined(NNBVH_BITS_LOGIC)
-#define NNBVH_KEY_LOGIC 1
-#elif defined(NNBVH_BITS_LOGIC)
-#define NNBVH_VALU_LOGIC 1
-#endif
 //
 // INST = 1: the scene is two-level (TransformedPrimitive leaves, cpu/primitive.cpp:112-131).  An
 // instance primitive saves the lane's ray state in LDS, transforms the ray with the reference's
@@ -534,14 +526,12 @@ void trace_kernel(TraceParams p) {
                 const int axis = __float_as_int(q3.z);
                 // aggregates.cpp:562-568: near child = second child iff dirIsNeg[axis]
                 const bool swap = ((r.kz >> axis) & 1) != 0;  // dirIsNeg[axis], packed by ray_shear
-#if defined(NNBVH_KEY_LOGIC)
                 // one float per child: its entry distance, +inf if the box is missed whatever tMax is
                 // (slab_entry_key) — the verdicts are then two compares against tMax
                 const float k0 = slab_entry_key(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r);
                 const float k1 = slab_entry_key(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r);
                 const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
                 const float nearT = swap ? k1 : k0, farT = swap ? k0 : k1;
-                const bool nearE = true;
                 visited += 1;  // the near child is entered now
                 // A far child whose tMax-independent tests failed (key +inf) can never be entered: it is
                 // counted now and not pushed.  One that merely fails against TODAY's tMax must be pushed:
@@ -561,56 +551,7 @@ void trace_kernel(TraceParams p) {
                 stk[sp & (W - 1)][1][lane] = farT;
                 sp += doPush ? 1 : 0;
                 if (MODE == 0 || MODE == 3) visited += doPush ? 0 : 1;
-#elif defined(NNBVH_VALU_LOGIC)
-                float t0, t1;
-                // verdicts as 0 / 1 integers in VGPRs and a push without a branch: the scalar unit, which
-                // this kernel keeps busier than the vector ALUs, drops out of the step's boolean algebra
-                const unsigned b0 = slab_partial_bits(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, t0);
-                const unsigned b1 = slab_partial_bits(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, t1);
-                const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
-                const unsigned nearB = swap ? b1 : b0, farB = swap ? b0 : b1;
-                const float nearT = swap ? t1 : t0, farT = swap ? t0 : t1;
-                const bool nearE = nearB != 0u, farE = farB != 0u;
-                visited += 1;  // the near child is entered now
-                const bool doPush = (MODE == 1) || farE;
-                // the window is kept at most W - 1 deep, so slot `sp` is always free and the far child can
-                // be written there unconditionally; it only counts if sp moves past it
-                if (doPush && sp - base == W - 1) {
-                    uint2 e;
-                    e.x = __float_as_uint(stk[base & (W - 1)][0][lane]);
-                    e.y = __float_as_uint(stk[base & (W - 1)][1][lane]);
-                    p.spill[(long)base * spillStride + gtid] = e;
-                    ++base;
-                }
-                stk[sp & (W - 1)][0][lane] = __int_as_float(farRef);
-                stk[sp & (W - 1)][1][lane] = farE ? farT : __builtin_inff();
-                sp += doPush ? 1 : 0;
-                if (MODE == 0 || MODE == 3) visited += doPush ? 0 : 1;  // popped and rejected later: same count
-#else
-                float t0, t1;
-                const bool e0 = slab_partial(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, t0);
-                const bool e1 = slab_partial(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, t1);
-                const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
-                const bool nearE = (swap & e1) | (!swap & e0), farE = (swap & e0) | (!swap & e1);
-                const float nearT = swap ? t1 : t0, farT = swap ? t0 : t1;
-                visited += 1;  // the near child is entered now
-                if (MODE == 1 || farE) {
-                    // push far child with its entry distance (+inf: box already missed)
-                    if (sp - base == W) {
-                        uint2 e;
-                        e.x = __float_as_uint(stk[base & (W - 1)][0][lane]);
-                        e.y = __float_as_uint(stk[base & (W - 1)][1][lane]);
-                        p.spill[(long)base * spillStride + gtid] = e;
-                        ++base;
-                    }
-                    stk[sp & (W - 1)][0][lane] = __int_as_float(farRef);
-                    stk[sp & (W - 1)][1][lane] = farE ? farT : __builtin_inff();
-                    ++sp;
-                } else if (MODE == 0 || MODE == 3) {
-                    visited += 1;  // the reference pops and rejects it later: same count
-                }
-#endif
-                if (nearE && nearT < tMax) cur = nearRef;
+                if (nearT < tMax) cur = nearRef;
                 else cur = pop_next();
                 }
             } while (++rep < p.intRepeat && __ballot(cur >= 0) != 0ull);

@@ -104,37 +104,6 @@ DEV bool slab_partial(float mnx, float mny, float mnz, float mxx, float mxy, flo
     return !(out1 | out2) & (tMax > 0.0f);
 }
 
-// The same test with its verdict kept as a 0 / 1 INTEGER in a vector register: every comparison
-// becomes v_cmp + v_cndmask and the conjunction v_and, so the scalar unit (which combines compare
-// masks with s_and_b64 in the form above, and is the busier unit of this kernel: DESIGN.md 5g) is
-// left out of it.  Same comparisons on the same values in the same orientation.
-DEV unsigned as_bit(bool c) {
-    unsigned v = c ? 1u : 0u;
-    asm volatile("" : "+v"(v));  // keeps the value in a VGPR: the compiler must not fold it back into a lane mask
-    return v;
-}
-DEV unsigned slab_partial_bits(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                               const RayState &r, float &tEntry) {
-    constexpr float widen = 1.0f + 2.0f * gamma_f(3);
-    float tMin = (((r.inv.x < 0.0f) ? mxx : mnx) - r.o.x) * r.inv.x;
-    float tMax = (((r.inv.x < 0.0f) ? mnx : mxx) - r.o.x) * r.inv.x;
-    float tyMin = (((r.inv.y < 0.0f) ? mxy : mny) - r.o.y) * r.inv.y;
-    float tyMax = (((r.inv.y < 0.0f) ? mny : mxy) - r.o.y) * r.inv.y;
-    tMax *= widen;
-    tyMax *= widen;
-    unsigned ok = as_bit(!(tMin > tyMax)) & as_bit(!(tyMin > tMax));
-    tMin = (tyMin > tMin) ? tyMin : tMin;
-    tMax = (tyMax < tMax) ? tyMax : tMax;
-    float tzMin = (((r.inv.z < 0.0f) ? mxz : mnz) - r.o.z) * r.inv.z;
-    float tzMax = (((r.inv.z < 0.0f) ? mnz : mxz) - r.o.z) * r.inv.z;
-    tzMax *= widen;
-    ok &= as_bit(!(tMin > tzMax)) & as_bit(!(tzMin > tMax));
-    tMin = (tzMin > tMin) ? tzMin : tMin;
-    tMax = (tzMax < tMax) ? tzMax : tMax;
-    tEntry = tMin;
-    return ok & as_bit(tMax > 0.0f);
-}
-
 // The same test reduced to ONE float per box: the entry distance if every test of the reference
 // other than `tMin < raytMax` passes, +inf otherwise — so that `key < raytMax` IS the reference's
 // verdict, now for the near child and later (against the then-current tMax) for a far child.
