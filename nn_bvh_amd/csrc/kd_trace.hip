@@ -443,9 +443,14 @@ static int kd_launch(nnbvh_kd_scene *s, int mode, const void *d_rays, int64_t n,
     p.n = (long)n;
     p.queue = w->queue;
     p.nQueues = kKdQueues;
-    p.primWeight = 24;
+    p.primWeight = 12;  // tools/kd_sweep.sh on bathroom: 12 / 8 / 4 is the best of 4 x 2 x 3 (+1.5 % over 24 / 8 / 4)
     p.refillWeight = 8;
     p.nodeRepeat = 4;
+#ifdef NNBVH_KD_TUNE  // tools only: scheduling knobs from the environment
+    if (const char *e = getenv("NNBVH_KD_PRIMW")) p.primWeight = atoi(e);
+    if (const char *e = getenv("NNBVH_KD_REFILLW")) p.refillWeight = atoi(e);
+    if (const char *e = getenv("NNBVH_KD_NODEREP")) p.nodeRepeat = atoi(e);
+#endif
     p.hasHostPrims = s->has_host_prims;
     p.spill = w->spill;
     // the four instances: closest / any hit x scenes with / without bilinear patches
