@@ -647,6 +647,7 @@ static int grid_blocks(nnbvh_scene *s, int mode) {
     if (per_cu <= 0) {
         TraceParams dummy{};
         dummy.hasHostPrims = s->has_host_prims;  // selects between the lean and the general instances
+        dummy.anim = s->d_anim;                  // ... and between the static- and the animated-instance ones
         int occ = 0;
         if (launch_trace(mode, dummy, s->window, s->instanced, s->has_patches + 2 * s->has_alpha, 0, nullptr, &occ) != hipSuccess ||
             occ <= 0)

@@ -204,7 +204,7 @@ void trace_kernel(TraceParams p) {
         cold[kInnerHit][lane] = 0.0f;
         V3 oIn, dIn;
         float4 m0 = s2, m1 = s3, m2 = s4;
-        if ((flags & kPrimAnimated) && p.anim)  // AnimatedPrimitive: Interpolate(r.time), primitive.cpp:143-144
+        if (INST == 2 && (flags & kPrimAnimated) && p.anim)  // AnimatedPrimitive: Interpolate(r.time), primitive.cpp:143-144
             anim_inverse_rows(p.anim + (long)kAnimStride * __float_as_int(s0.w), cold[kColdTime][lane], m0, m1, m2);
         apply_inverse_ray(m0, m1, m2, r.o, dOuter, tMax, oIn, dIn);
         r.o = oIn;
@@ -579,7 +579,8 @@ static hipError_t launch_one(const TraceParams &p, int blocks, hipStream_t strea
 static hipError_t launch_fused(const TraceParams &p, int window, int instanced, int patches, int blocks,
                                hipStream_t stream, int *occupancy) {
     if (window != 8 || (patches & 2)) return hipErrorInvalidValue;
-    if (instanced) return launch_one<3, 8, 1, 1>(p, blocks, stream, occupancy);
+    if (instanced) return p.anim ? launch_one<3, 8, 2, 1>(p, blocks, stream, occupancy)
+                                 : launch_one<3, 8, 1, 1>(p, blocks, stream, occupancy);
     if (!patches && !p.hasHostPrims) return launch_one<3, 8, 0, 0>(p, blocks, stream, occupancy);
     return launch_one<3, 8, 0, 1>(p, blocks, stream, occupancy);
 }
@@ -588,9 +589,15 @@ template <int MODE>
 static hipError_t launch_mode(const TraceParams &p, int window, int instanced, int patches, int blocks,
                               hipStream_t stream, int *occupancy) {
     // scenes with alpha-tested triangles and two-level scenes: one instance of the kernel each (window 8)
-    if (patches & 2) return instanced ? launch_one<MODE, 8, 1, 1, 1>(p, blocks, stream, occupancy)
-                                      : launch_one<MODE, 8, 0, 1, 1>(p, blocks, stream, occupancy);
-    if (instanced) return launch_one<MODE, 8, 1, 1>(p, blocks, stream, occupancy);
+    // INST: 0 single-level, 1 static instances, 2 instances with AnimatedPrimitives among them (the
+    // interpolation of the transform costs 60 VGPRs: 160-177 against 98-116, 2 against 3 wavefronts per SIMD)
+    if (patches & 2) {
+        if (!instanced) return launch_one<MODE, 8, 0, 1, 1>(p, blocks, stream, occupancy);
+        return p.anim ? launch_one<MODE, 8, 2, 1, 1>(p, blocks, stream, occupancy)
+                      : launch_one<MODE, 8, 1, 1, 1>(p, blocks, stream, occupancy);
+    }
+    if (instanced) return p.anim ? launch_one<MODE, 8, 2, 1>(p, blocks, stream, occupancy)
+                                 : launch_one<MODE, 8, 1, 1>(p, blocks, stream, occupancy);
     if (!patches && !p.hasHostPrims && window == 8) return launch_one<MODE, 8, 0, 0>(p, blocks, stream, occupancy);
     switch (window) {
     case 4: return launch_one<MODE, 4, 0, 1>(p, blocks, stream, occupancy);
