@@ -115,8 +115,62 @@ def compare(agg, tree, verts, rays):
     return sorted(bad), exp
 
 
+def compare_kd(verts, prims, rays, max_prims):
+    """The same rays through KdTreeAggregate (kd_trace.hip) against the oracle's kd traversal."""
+    from nn_bvh_amd.kdtree import KdTreeAggregate, build_kd_tree
+    tree = build_kd_tree(prims, verts, max_prims=max_prims)
+    agg = KdTreeAggregate.from_tree(tree.nodes, tree.prim_indices, prims, verts, tree.bounds)
+    exp = ob.kd_closest(tree.nodes, tree.prim_indices, prims, verts, tree.bounds, rays, 8)
+    got = agg.Intersect(rays)
+    bad = set()
+    for f in ("prim", "nodes_visited", "prim_tests"):
+        bad |= set(np.nonzero(got[f] != exp[f])[0].tolist())
+    for f in ("t", "b0", "b1", "b2"):
+        differ = (got[f].view(np.uint32) != exp[f].view(np.uint32)) & ~(np.isnan(got[f]) & np.isnan(exp[f]))
+        bad |= set(np.nonzero(differ)[0].tolist())
+    eocc, evis, etst = ob.kd_any_hit(tree.nodes, tree.prim_indices, prims, verts, tree.bounds, rays, 8)
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    bad |= set(np.nonzero((occ != eocc) | (vis != evis) | (tst != etst))[0].tolist())
+    bad |= set(np.nonzero(agg.IntersectP(rays) != eocc)[0].tolist())
+    if bad and os.environ.get("FUZZ_VERBOSE"):
+        i = sorted(bad)[0]
+        print("  kd ray", rays[i], " oracle", exp[i], " device", got[i], " any", eocc[i], evis[i], etst[i], occ[i], vis[i], tst[i])
+    agg.close()
+    return sorted(bad)
+
+
+def compare_two_level(seed, n_rays):
+    """A random two-level scene (test_instancing.two_level_scene: two object definitions placed with
+    random affine transforms + top-level triangles) through the INST kernels against the oracle."""
+    from test_instancing import two_level_scene
+    rng = np.random.default_rng(seed)
+    verts, nodes, prims, instances, n_top, _ = two_level_scene(int(rng.integers(0, 1 << 20)), int(rng.integers(2, 40)))
+    lo = np.array([-30, -30, -30.0])
+    rays = np.concatenate([scene.random_rays(n_rays // 2, lo, -lo, seed), draw_rays(rng, verts, prims[prims["kind"] != 2], n_rays // 2)])
+    agg = BVHAggregate.from_tree(nodes, prims, verts, instances=instances, n_top_nodes=n_top)
+    exp = ob.closest_inst(nodes, prims, verts, instances, rays, 8)
+    got = agg.Intersect(rays)
+    bad = set()
+    for f in ("prim", "nodes_visited", "prim_tests", "instance"):
+        bad |= set(np.nonzero(got[f] != exp[f])[0].tolist())
+    for f in ("t", "b0", "b1", "b2"):
+        differ = (got[f].view(np.uint32) != exp[f].view(np.uint32)) & ~(np.isnan(got[f]) & np.isnan(exp[f]))
+        bad |= set(np.nonzero(differ)[0].tolist())
+    eocc, evis, etst = ob.any_hit_inst(nodes, prims, verts, instances, rays, 8)
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    bad |= set(np.nonzero((occ != eocc) | (vis != evis) | (tst != etst))[0].tolist())
+    bad |= set(np.nonzero(agg.IntersectP(rays) != eocc)[0].tolist())
+    if bad and os.environ.get("FUZZ_VERBOSE"):
+        i = sorted(bad)[0]
+        print("  two-level ray", rays[i], " oracle", exp[i], " device", got[i], " any", eocc[i], evis[i], etst[i], occ[i], vis[i], tst[i])
+    agg.close()
+    return sorted(bad)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--kd", action="store_true", help="also trace every scene's kd-tree")
+    ap.add_argument("--two-level", type=int, default=0, metavar="K", help="every K-th iteration also checks a random instanced scene")
     ap.add_argument("--iterations", type=int, default=100)
     ap.add_argument("--rays", type=int, default=8000)
     ap.add_argument("--seed", type=int, default=1)
@@ -135,6 +189,16 @@ def main():
             agg.set_option("stack_window", int(rng.choice([4, 16])))
         rays = draw_rays(rng, verts, prims, args.rays)
         bad, exp = compare(agg, tree, verts, rays)
+        if args.kd:
+            kbad = compare_kd(verts, prims, rays, max_prims=int(rng.choice([1, 4])))
+            if kbad:
+                print(f"KD MISMATCH seed {seed}: {len(kbad)} rays, first {kbad[:5]}", flush=True)
+                bad = bad + kbad
+        if args.two_level and it % args.two_level == 0:
+            tbad = compare_two_level(seed, args.rays)
+            if tbad:
+                print(f"TWO-LEVEL MISMATCH seed {seed}: {len(tbad)} rays, first {tbad[:5]}", flush=True)
+                bad = bad + tbad
         total += len(rays)
         if bad:
             failures += 1
