@@ -35,12 +35,12 @@ def build_stats(verbose=False):
     return out
 
 
-def build_variant(name, defines, verbose=False):
-    """Experimental build nn_bvh_amd/libnnbvh_hip_<name>.so with extra -D flags (select it with
-    NNBVH_LIB=libnnbvh_hip_<name>.so); never the product."""
+def build_variant(name, defines, verbose=False, flags=()):
+    """Experimental build nn_bvh_amd/libnnbvh_hip_<name>.so with extra -D flags (and compiler flags; select
+    it with NNBVH_LIB=libnnbvh_hip_<name>.so); never the product."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = os.path.join(HERE, f"libnnbvh_hip_{name}.so")
-    cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + list(flags) + [f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
