@@ -642,12 +642,19 @@ int nnbvh_scene_bounds(const nnbvh_scene *s, float out[6]) {
 // Persistent grid = what is resident at once (register/LDS limited), asked from the runtime
 // for the exact kernel instance.  The kernel needs no co-residency (no grid barrier; late
 // blocks just find less work in the queues), so a wrong answer costs speed, never results.
+// both device arrays below 4 GiB (64 B per interior record, 16 B per primitive slot): the lean
+// kernel instances reach them with 32-bit byte offsets
+static int scene_fits32(const nnbvh_scene *s) {
+    return (int64_t)s->n_interior < (1LL << 26) && s->n_slots < (1LL << 28) - 8;
+}
+
 static int grid_blocks(nnbvh_scene *s, int mode) {
     int per_cu = s->blocks_per_cu;
     if (per_cu <= 0) {
         TraceParams dummy{};
         dummy.hasHostPrims = s->has_host_prims;  // selects between the lean and the general instances
         dummy.anim = s->d_anim;                  // ... and between the static- and the animated-instance ones
+        dummy.fits32 = scene_fits32(s);
         int occ = 0;
         if (launch_trace(mode, dummy, s->window, s->instanced, s->has_patches + 2 * s->has_alpha, 0, nullptr, &occ) != hipSuccess ||
             occ <= 0)
@@ -785,6 +792,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     p.stats = s->d_stats;
     p.intRepeat = s->int_repeat;
     p.primRepeat = s->prim_repeat;
+    p.fits32 = scene_fits32(s);
     p.hasHostPrims = s->has_host_prims;
     p.spill = w->spill;
     p.anim = s->d_anim;
@@ -895,6 +903,7 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
         p.stats = s->d_stats;
         p.intRepeat = s->int_repeat;
         p.primRepeat = s->prim_repeat;
+        p.fits32 = scene_fits32(s);
         p.hasHostPrims = s->has_host_prims;
         p.spill = w->spill;
         p.anim = s->d_anim;

@@ -33,6 +33,7 @@ struct TraceParams {
     int hasHostPrims;       // scene contains NNBVH_PRIM_HOST primitives
     int intRepeat;          // interior steps per scheduling decision (>= 1)
     int primRepeat;         // primitive steps per scheduling decision (>= 1)
+    int fits32;             // wide[] and prims[] are both below 4 GiB: the lean instances' 32-bit offsets reach them
     unsigned long long *stats;  // NNBVH_STATS builds: trips/lanes per step kind; else unused
     uint2 *spill;           // [kMaxStack][grid threads] overflow of the LDS stack window
     const float *anim;      // two-level scenes: kAnimStride floats per instance (anim_math.h), or null

@@ -417,7 +417,9 @@ void trace_kernel(TraceParams p) {
                 if (INST && cur == kReturn) leave_instance();
                 if (cur < 0 && cur != kDone && cur != kReturn) {
                     const int slot = ~cur;
-                    float4 s0 = p.prims[slot], s1 = p.prims[slot + 1], s2 = p.prims[slot + 2];
+                    const float4 *pr = kLean ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.prims) + ((unsigned)slot << 4))
+                                             : p.prims + slot;
+                    float4 s0 = pr[0], s1 = pr[1], s2 = pr[2];
                     // all three slots are fetched before anything looks at the flags: left alone the compiler
                     // loads the flag word first and the vertices only inside the not-degenerate branch, two
                     // dependent trips to memory per primitive
@@ -519,7 +521,11 @@ void trace_kernel(TraceParams p) {
 #pragma unroll
                 for (int k = 0; k < NNBVH_PROBE_VALU; ++k) asm volatile("v_add_u32 %0, %0, 1" : "+v"(tests));
 #endif
-                const float4 *rec = p.wide + 4 * (long)cur;
+                // lean instances address records and slots with a 32-bit byte offset from a scalar base (one
+                // 32-bit shift instead of a 64-bit shift and a 64-bit add per fetch); the launcher only picks
+                // them when both arrays are below 4 GiB (p.fits32)
+                const float4 *rec = kLean ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.wide) + ((unsigned)cur << 6))
+                                          : p.wide + 4 * (long)cur;
                 const float4 q3 = rec[3];
                 const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
                 const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
@@ -581,7 +587,7 @@ static hipError_t launch_fused(const TraceParams &p, int window, int instanced, 
     if (window != 8 || (patches & 2)) return hipErrorInvalidValue;
     if (instanced) return p.anim ? launch_one<3, 8, 2, 1>(p, blocks, stream, occupancy)
                                  : launch_one<3, 8, 1, 1>(p, blocks, stream, occupancy);
-    if (!patches && !p.hasHostPrims) return launch_one<3, 8, 0, 0>(p, blocks, stream, occupancy);
+    if (!patches && !p.hasHostPrims && p.fits32) return launch_one<3, 8, 0, 0>(p, blocks, stream, occupancy);
     return launch_one<3, 8, 0, 1>(p, blocks, stream, occupancy);
 }
 
@@ -598,7 +604,7 @@ static hipError_t launch_mode(const TraceParams &p, int window, int instanced, i
     }
     if (instanced) return p.anim ? launch_one<MODE, 8, 2, 1>(p, blocks, stream, occupancy)
                                  : launch_one<MODE, 8, 1, 1>(p, blocks, stream, occupancy);
-    if (!patches && !p.hasHostPrims && window == 8) return launch_one<MODE, 8, 0, 0>(p, blocks, stream, occupancy);
+    if (!patches && !p.hasHostPrims && p.fits32 && window == 8) return launch_one<MODE, 8, 0, 0>(p, blocks, stream, occupancy);
     switch (window) {
     case 4: return launch_one<MODE, 4, 0, 1>(p, blocks, stream, occupancy);
     case 8: return launch_one<MODE, 8, 0, 1>(p, blocks, stream, occupancy);
