@@ -87,8 +87,15 @@ DEV bool kd_root_interval(const float bmin[3], const float bmax[3], V3 o, V3 inv
 // fetched except `ray.d[axis] <= 0` at interior nodes, which rides as three bits beside the shear's
 // kz; the patch test, the largest register consumer, is not compiled in.
 // W: entries per lane of the LDS window of the to-visit stack.
-template <int MODE, int PATCH, int W>
+// O32: nodes, primitive records and primitiveIndices are each below 4 GiB and are fetched through 32-bit
+// byte offsets from a scalar base (no 64-bit shift / add per fetch).
+template <int MODE, int PATCH, int W, int O32>
 __global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdParams p) {
+    auto at = [](const auto *base, int index) {  // &base[index]
+        using T = decltype(base);
+        return O32 ? reinterpret_cast<T>(reinterpret_cast<const char *>(base) + (unsigned)index * (unsigned)sizeof(*base))
+                   : base + (long)index;
+    };
     // KdNodeToVisit {node, tMin, tMax}: the three words of an entry 64 dwords apart
     __shared__ float s_stack[kKdBlock / 64][W][3][64];
     // cold per-ray state ([field][lane]): ray index, best hit (closest), reached-a-host-primitive flag
@@ -234,10 +241,10 @@ __global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdPar
             if (cur == kKdLeaf) {
                 // one trip to memory: the primitive's three slots and — if the leaf goes on — the index of
                 // the primitive after it, all issued before anything is looked at
-                const float4 *rec = p.prims + 4 * (long)leafIdx;
+                const float4 *rec = at(p.prims, 4 * leafIdx);
                 float4 s0 = rec[0], s1 = rec[1], s2 = rec[2];
                 int nextIdx = 0;
-                if (leafLeft > 1) nextIdx = p.primIndices[leafPos];
+                if (leafLeft > 1) nextIdx = *at(p.primIndices, leafPos);
                 asm volatile("" : "+v"(s0.x), "+v"(s0.y), "+v"(s0.z), "+v"(s0.w), "+v"(s1.x), "+v"(s1.y),
                                   "+v"(s1.z), "+v"(s1.w), "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(nextIdx));
                 const unsigned flags = __float_as_uint(s1.w);
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdPar
                         cur = kKdDone;
                     } else {
                         visited += 1;
-                        const uint2 nd = p.nodes[cur];
+                        const uint2 nd = *at(p.nodes, cur);
                         const unsigned flags = nd.y;
                         if ((flags & 3u) != 3u) {
                             // interior (:993-1023 / :1110-1144)
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdPar
                             } else {
                                 leafLeft = nPrimitives;
                                 leafPos = (int)nd.x + 1;
-                                leafIdx = nPrimitives == 1 ? (int)nd.x : p.primIndices[(int)nd.x];
+                                leafIdx = nPrimitives == 1 ? (int)nd.x : *at(p.primIndices, (int)nd.x);
                                 cur = kKdLeaf;
                             }
                         }
@@ -404,6 +411,7 @@ struct nnbvh_kd_scene {
     int depth = 0;
     int has_host_prims = 0;
     int has_patches = 0;
+    int fits32 = 0;  // nodes (8 B), primitive records (64 B) and indices (4 B) each below 4 GiB
     float bounds[6];
     uint2 *d_nodes = nullptr;
     int32_t *d_indices = nullptr;
@@ -454,9 +462,11 @@ static int kd_launch(nnbvh_kd_scene *s, int mode, const void *d_rays, int64_t n,
     p.hasHostPrims = s->has_host_prims;
     p.spill = w->spill;
     // the four instances: closest / any hit x scenes with / without bilinear patches
-    void (*const kernels[4])(KdParams) = {kd_trace_kernel<0, 0, kKdWLean>, kd_trace_kernel<1, 0, kKdWLean>,
-                                          kd_trace_kernel<0, 1, kKdW>, kd_trace_kernel<1, 1, kKdW>};
-    void (*const kernel)(KdParams) = kernels[mode + 2 * s->has_patches];
+    void (*const kernels[8])(KdParams) = {
+        kd_trace_kernel<0, 0, kKdWLean, 0>, kd_trace_kernel<1, 0, kKdWLean, 0>, kd_trace_kernel<0, 1, kKdW, 0>,
+        kd_trace_kernel<1, 1, kKdW, 0>,     kd_trace_kernel<0, 0, kKdWLean, 1>, kd_trace_kernel<1, 0, kKdWLean, 1>,
+        kd_trace_kernel<0, 1, kKdW, 1>,     kd_trace_kernel<1, 1, kKdW, 1>};
+    void (*const kernel)(KdParams) = kernels[mode + 2 * s->has_patches + 4 * s->fits32];
     if (s->blocks_per_cu[mode] == 0) {
         int occ = 0;
         const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kKdBlock, 0);
@@ -588,6 +598,7 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
     s->depth = max_depth;
     s->has_host_prims = has_host ? 1 : 0;
     s->has_patches = has_patch ? 1 : 0;
+    s->fits32 = (n_nodes < (1 << 29) && n_prims < (1 << 26) - 1 && n_indices < (1 << 30)) ? 1 : 0;
     std::memcpy(s->bounds, bounds_min_max, 24);
     const size_t ni = (size_t)std::max(n_indices, 1);
     bool ok = kd_hip_ok(hipMalloc((void **)&s->d_nodes, (size_t)n_nodes * 8), "hipMalloc(kd nodes)") &&
