@@ -506,8 +506,7 @@ void trace_kernel(TraceParams p) {
         } else {
             // ---- interior step(s): up to p.intRepeat in a row before the next scheduling
             // decision (lanes that leave the interior state sit the remaining ones out) -------
-            int rep = 0;
-            do {
+            auto interior_step = [&]() {
 #ifdef NNBVH_STATS
                 st[14] += 1;
                 st[15] += __popcll(__ballot(cur >= 0));
@@ -560,7 +559,24 @@ void trace_kernel(TraceParams p) {
                 if (nearT < tMax) cur = nearRef;
                 else cur = pop_next();
                 }
+            };
+            if (MODE == 3) {
+                // the one-launch kernel: the first three steps (the default int_repeat) written out, no trip
+                // counter to maintain (+0.8 %; the separate-launch kernels lose 1.8 % with it and keep the loop)
+                interior_step();
+                if (p.intRepeat > 1 && __ballot(cur >= 0) != 0ull) {
+                    interior_step();
+                    if (p.intRepeat > 2 && __ballot(cur >= 0) != 0ull) {
+                        interior_step();
+                        for (int rep = 3; rep < p.intRepeat && __ballot(cur >= 0) != 0ull; ++rep) interior_step();
+                    }
+                }
+            } else {
+            int rep = 0;
+            do {
+                interior_step();
             } while (++rep < p.intRepeat && __ballot(cur >= 0) != 0ull);
+            }
         }
     }
 #ifdef NNBVH_STATS
