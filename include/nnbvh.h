@@ -501,7 +501,8 @@ int nnbvh_kd_intersect_any_device(nnbvh_kd_scene *s, const void *d_rays, int64_t
  * "blocks_per_cu" (0 = auto), "xcd_queues" (0/1), "prim_weight" / "refill_weight" (1..64: how much a
  * lane waiting on a primitive test / an idle lane counts against a lane waiting on an interior node,
  * which counts 16, when a wavefront picks its next step), "int_repeat" / "prim_repeat" (1..16
- * interior / primitive steps per scheduling decision), "fused_batches" (0/1: nnbvh_trace_batches_device as one launch where the
+ * interior / primitive steps per scheduling decision; the kernel instances for scenes without patches,
+ * instances and host-only primitives always take one primitive step), "fused_batches" (0/1: nnbvh_trace_batches_device as one launch where the
  * batches allow it).  Returns NNBVH_ERR_ARG for unknown keys. */
 int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value);
 

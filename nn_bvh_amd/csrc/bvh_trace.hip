@@ -409,8 +409,9 @@ void trace_kernel(TraceParams p) {
             // ---- primitive step: lanes with a pending leaf test ONE primitive -----------
             // (up to p.primRepeat of them per scheduling decision: lanes whose leaf is finished sit the
             // rest out, lanes still inside theirs go on without another round of ballots)
-            // (the one-launch kernel keeps ONE: the loop costs it registers and 8 % of its rate)
-            const int nPrep = (MODE == 3 && !NNBVH_FUSED_PRIM_LOOP) ? 1 : p.primRepeat;
+            // (the one-launch kernel and the lean instances keep ONE: compiled in, the loop costs them 6
+            // registers — spills at 8 wavefronts per SIMD — and 2.6 % / 8 % of their rate)
+            const int nPrep = ((MODE == 3 && !NNBVH_FUSED_PRIM_LOOP) || kLean) ? 1 : p.primRepeat;
             int prep = 0;
             do {
             if (cur < 0 && cur != kDone) {
