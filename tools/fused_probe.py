@@ -19,7 +19,6 @@ def main():
     ap.add_argument("--intrepeat", default="3")
     ap.add_argument("--primweight", default="32")
     ap.add_argument("--refill", default="8")
-    ap.add_argument("--grab", default="0", help="grab_chunk values")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--spp", type=int, default=8)
     args = ap.parse_args()
@@ -53,13 +52,11 @@ def main():
     combos = list(itertools.product([int(x) for x in args.primrepeat.split(",")],
                                     [int(x) for x in args.intrepeat.split(",")],
                                     [int(x) for x in args.primweight.split(",")],
-                                    [int(x) for x in args.refill.split(",")],
-                                    [int(x) for x in args.grab.split(",")]))
+                                    [int(x) for x in args.refill.split(",")]))
     times = {(c, k): [] for c in combos for k in ("fused", "serial")}
     for rnd in range(args.rounds + 1):
         for c in combos:
-            for key, v in (("prim_repeat", c[0]), ("int_repeat", c[1]), ("prim_weight", c[2]), ("refill_weight", c[3]),
-                           ("grab_chunk", c[4])):  # grab_chunk: an experiment of round 2, not in the product
+            for key, v in (("prim_repeat", c[0]), ("int_repeat", c[1]), ("prim_weight", c[2]), ("refill_weight", c[3])):
                 try:
                     agg.set_option(key, v)
                 except Exception:  # an older experimental build without the knob
@@ -73,10 +70,10 @@ def main():
                 if rnd:
                     times[(c, k)].append(a.elapsed_time(b))
     print(f"# {source}; {n} rays per step")
-    print("prim_repeat int_repeat prim_weight refill_weight grab_chunk | one launch ms (Mray/s) | three launches ms (Mray/s)")
+    print("prim_repeat int_repeat prim_weight refill_weight | one launch ms (Mray/s) | three launches ms (Mray/s)")
     for c in combos:
         f, s = np.median(times[(c, "fused")]), np.median(times[(c, "serial")])
-        print(f"{c[0]:11d} {c[1]:10d} {c[2]:11d} {c[3]:13d} {c[4]:10d} | {f:8.3f} ({n / f / 1e3:7.1f}) | {s:8.3f} ({n / s / 1e3:7.1f})", flush=True)
+        print(f"{c[0]:11d} {c[1]:10d} {c[2]:11d} {c[3]:13d} | {f:8.3f} ({n / f / 1e3:7.1f}) | {s:8.3f} ({n / s / 1e3:7.1f})", flush=True)
 
 
 if __name__ == "__main__":
