@@ -649,8 +649,13 @@ uint64_t orc_hash_6f(const float a[3], const float b[3]);
 float orc_hash_float_6f(const float a[3], const float b[3]);
 void orc_offset_ray_origin(const float lo[3], const float hi[3], const float n[3], const float w[3], float po[3]);
 
+/* The re-trace after a rejected hit (:63-69) is the reference's recursion unrolled ONCE: for a planar
+ * triangle the ray spawned off its own surface cannot hit it again, and the recursion ends there.  Only
+ * degenerate rays (NaN / zero direction, NaN tHit) make the second test succeed, and then the reference
+ * recurses without bound; the library's contract for that case is "the record is void, the caller
+ * re-traces the ray" (*host_io = 1), and this restatement follows it instead of overflowing the stack. */
 static int alpha_intersect(const orc_prim *p, const float *verts, const float o[3], const float d[3],
-                           float tmax, float res[4], int *tests) {
+                           float tmax, float res[4], int *tests, int *host_io) {
     float r[4];
     ++*tests;
     if (!prim_test(p, verts, o, d, tmax, r)) return 0; /* :52-54 */
@@ -666,10 +671,9 @@ static int alpha_intersect(const orc_prim *p, const float *verts, const float o[
             memcpy(p9 + 6, verts + 3 * (size_t)p->v[2], 12);
             orc_triangle_interaction(p9, NULL, NULL, NULL, p->kind == 5, r, wo, 0.0f, 0, rec);
             orc_offset_ray_origin(rec + 38, rec + 41, rec + 11, d, on);
-            if (!alpha_intersect(p, verts, on, d, tmax - r[3], rn, tests)) return 0;
-            rn[3] += r[3]; /* siNext->tHit += si->tHit */
-            memcpy(res, rn, 16);
-            return 1;
+            ++*tests; /* Triangle::Intersect counts the re-test too */
+            if (prim_test(p, verts, on, d, tmax - r[3], rn)) *host_io = 1;
+            return 0;
         }
     }
     memcpy(res, r, 16);
@@ -719,7 +723,7 @@ static void closest_tree(const orc_node *nodes, const orc_prim *prims, const flo
                     }
                     int primHit;
                     if (p->kind == 4 || p->kind == 5) {
-                        primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests);
+                        primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests, host_io);
                     } else {
                         ++tests;
                         primHit = prim_test(p, verts, o, d, tmax, r);
@@ -806,7 +810,7 @@ static int any_tree(const orc_node *nodes, const orc_prim *prims, const float *v
                     }
                     int primHit; /* GeometricPrimitive::IntersectP with alpha = Intersect(...).has_value(), :79-81 */
                     if (p->kind == 4 || p->kind == 5) {
-                        primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests);
+                        primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests, host_io);
                     } else {
                         ++tests;
                         primHit = prim_test(p, verts, o, d, tmax, r);

@@ -23,6 +23,7 @@ import oracle_binding as ob  # noqa: E402
 import scenes_small as ss  # noqa: E402
 from nn_bvh_amd import BVHAggregate, build_tree, make_rays, scene  # noqa: E402
 
+ALPHA_SHARE = 0.0  # --alpha: share of scenes with alpha-tested triangles
 SPECIAL = np.array([0.0, -0.0, 1.0, -1.0, 0.5, np.inf, -np.inf, 1e-30, -1e-30, np.nan], np.float32)
 
 
@@ -39,6 +40,14 @@ def draw_scene(rng):
         verts, prims = ss.coincident_centroids(int(rng.integers(5, 150)), seed)
     if rng.random() < 0.5:  # snap to a coarse grid: coincident planes, flat boxes, degenerate triangles
         verts = (np.round(verts * 4) / 4).astype(np.float32)
+    if ALPHA_SHARE and rng.random() < ALPHA_SHARE:
+        # constant-alpha GeometricPrimitives (kinds 4 / 5, cpu/primitive.cpp:50-84) among the triangles
+        prims = prims.copy()
+        tri = prims["kind"] == 0
+        kinds = rng.choice(np.array([0, 4, 5], np.int32), len(prims), p=[0.4, 0.3, 0.3])
+        alpha = rng.choice(np.array([0.0, 0.25, 0.5, 0.9, 1.0, 1.5, -0.5], np.float32), len(prims))
+        prims["kind"] = np.where(tri, kinds, prims["kind"])
+        prims["v"][:, 3] = np.where(tri & (kinds != 0), alpha.view(np.int32), prims["v"][:, 3])
     return verts, prims
 
 
@@ -82,7 +91,7 @@ def compare(agg, tree, verts, rays):
     exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, nthreads=8)
     got = agg.Intersect(rays)
     bad = set()
-    for f in ("prim", "nodes_visited", "prim_tests"):
+    for f in ("prim", "nodes_visited", "prim_tests", "instance"):  # instance = -1: the record is void (host)
         bad |= set(np.nonzero(got[f] != exp[f])[0].tolist())
     for f in ("t", "b0", "b1", "b2"):  # bit patterns; a NaN equals a NaN (x86 and gfx950 differ in the default NaN's sign)
         differ = (got[f].view(np.uint32) != exp[f].view(np.uint32)) & ~(np.isnan(got[f]) & np.isnan(exp[f]))
@@ -170,11 +179,14 @@ def compare_two_level(seed, n_rays):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kd", action="store_true", help="also trace every scene's kd-tree")
+    ap.add_argument("--alpha", type=float, default=0.0, help="share of scenes with alpha-tested triangles")
     ap.add_argument("--two-level", type=int, default=0, metavar="K", help="every K-th iteration also checks a random instanced scene")
     ap.add_argument("--iterations", type=int, default=100)
     ap.add_argument("--rays", type=int, default=8000)
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
+    global ALPHA_SHARE
+    ALPHA_SHARE = args.alpha
     failures = 0
     total = 0
     for it in range(args.iterations):

@@ -55,6 +55,28 @@ def test_oracle_alpha_semantics():
     assert np.array_equal(occ == 1, h["prim"] >= 0)
 
 
+def test_oracle_alpha_retrace_is_unrolled_once_and_degenerate_rays_terminate():
+    """primitive.cpp:63-69 recurses on the ray spawned off the rejected hit.  A planar triangle cannot be
+    hit by it again; rays with NaN / zero components can, and the reference then recurses without bound.
+    The restatement unrolls the recursion once and follows the library's contract for a second hit (the
+    record is void: instance = -1 / occluded = 2) instead of overflowing the stack."""
+    verts, prims, alpha, kinds = alpha_scene(9, 800)
+    tree = build_tree(prims, verts)
+    rng = np.random.default_rng(3)
+    rays = scene.random_rays(6000, verts.min(0) - 1, verts.max(0) + 1, 11)
+    special = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-30], np.float32)
+    for f in ("o", "d"):
+        v = rays[f].copy()
+        m = rng.random(v.shape) < 0.15
+        v[m] = rng.choice(special, int(m.sum()))
+        rays[f] = v
+    h = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, 4)  # must return
+    occ, _, _ = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, 4)
+    void = h["instance"] == -1
+    assert np.array_equal(occ[void & (h["prim"] < 0)] == 2, np.ones(int((void & (h["prim"] < 0)).sum()), bool))
+    assert set(np.unique(h["instance"])) <= {0, -1}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("how", ["host_tree", "device_build"])
 def test_device_alpha_equals_oracle(how):
