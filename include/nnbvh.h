@@ -481,7 +481,8 @@ void nnbvh_kd_build_destroy(nnbvh_kd_build *b);
 
 /* The tree is validated (child links, leaf ranges, primitive indices, depth <= 64 = the reference's
  * toVisit[64], aggregates.cpp:982) before anything is uploaded.  prims: n_prims primitives indexed
- * by the leaves; hit.prim reports nnbvh_prim.id. */
+ * by the leaves (triangles, alpha-tested triangles NNBVH_PRIM_ALPHA_TRIANGLE[_FLIPPED], bilinear
+ * patches, host-only primitives); hit.prim reports nnbvh_prim.id. */
 nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, const int32_t *prim_indices,
                                       int n_indices, const nnbvh_prim *prims, int n_prims,
                                       const float *verts, int n_verts, const float bounds_min_max[6],

@@ -200,7 +200,7 @@ nnbvh_kd_build *nnbvh_kd_build_create(const nnbvh_prim *prims, int n_prims, cons
     KBox bounds;
     for (int i = 0; i < n_prims; ++i) {
         const nnbvh_prim &p = prims[i];
-        const int nv = p.kind == NNBVH_PRIM_TRIANGLE ? 3 : p.kind == NNBVH_PRIM_BILINEAR_PATCH ? 4 : 0;
+        const int nv = nnbvh::is_triangle_kind(p.kind) ? 3 : p.kind == NNBVH_PRIM_BILINEAR_PATCH ? 4 : 0;  // kinds 4 / 5: alpha-tested triangles
         KBox b;
         if (p.kind == NNBVH_PRIM_HOST) {
             if (!prim_bounds) {
@@ -210,7 +210,7 @@ nnbvh_kd_build *nnbvh_kd_build_create(const nnbvh_prim *prims, int n_prims, cons
             std::memcpy(b.mn, prim_bounds + 6 * (size_t)i, 12);
             std::memcpy(b.mx, prim_bounds + 6 * (size_t)i + 3, 12);
         } else if (!nv) {
-            nnbvh::set_error("nnbvh_kd_build_create: unsupported primitive kind (triangles, patches, host primitives)");
+            nnbvh::set_error("nnbvh_kd_build_create: unsupported primitive kind (triangles, alpha-tested triangles, patches, host primitives)");
             return nullptr;
         } else {
             const float *v[4] = {nullptr, nullptr, nullptr, nullptr};

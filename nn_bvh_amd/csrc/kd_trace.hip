@@ -27,6 +27,7 @@
 #include "../../include/nnbvh.h"
 #include "nnbvh_internal.h"
 #include "trace_math.h"
+#include "spawn_math.h"
 
 namespace nnbvh {
 
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdPar
                 int nextIdx = 0;
                 if (leafLeft > 1) nextIdx = *at(p.primIndices, leafPos);
                 asm volatile("" : "+v"(s0.x), "+v"(s0.y), "+v"(s0.z), "+v"(s0.w), "+v"(s1.x), "+v"(s1.y),
-                                  "+v"(s1.z), "+v"(s1.w), "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(nextIdx));
+                                  "+v"(s1.z), "+v"(s1.w), "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(s2.w), "+v"(nextIdx));
                 const unsigned flags = __float_as_uint(s1.w);
                 if (flags & kPrimHost) {
                     cold[kColdHost][lane] = 1.0f;
@@ -257,6 +258,26 @@ __global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdPar
                     if (!PATCH || !(flags & kPrimPatch)) {
                         hit = triangle_test(r, rayTMax, (flags & kPrimDegenerate) != 0, {s0.x, s0.y, s0.z},
                                             {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z}, x0, x1, x2, th);
+                        if (PATCH && hit && (flags & kPrimAlpha)) {
+                            // GeometricPrimitive::Intersect / IntersectP with a constant alpha (cpu/primitive.cpp:
+                            // 57-70, 79-81), as in the BVH kernels; scenes with such primitives run the PATCH
+                            // instances, which keep the ray direction
+                            const float a = s2.w;
+                            if (a < 1) {
+                                const float u = (a <= 0) ? 1.f : hash_float_6f(r.o, d);
+                                if (u > a) {
+                                    hit = false;
+                                    RayState rn = r;
+                                    rn.o = alpha_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z},
+                                                                x0, x1, x2, (flags & kPrimFlipN) != 0, d);
+                                    tests += 1;  // Triangle::Intersect counts the re-test too
+                                    float y0, y1, y2, tn;
+                                    if (triangle_test(rn, rayTMax - th, (flags & kPrimDegenerate) != 0, {s0.x, s0.y, s0.z},
+                                                      {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z}, y0, y1, y2, tn))
+                                        cold[kColdHost][lane] = 1.0f;  // the ray is the caller's (see bvh_trace.hip)
+                                }
+                            }
+                        }
                     } else {
                         const float4 s3 = rec[3];
                         x2 = 0.0f;
@@ -562,8 +583,16 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
         if (pr.kind == NNBVH_PRIM_HOST) {
             flags |= kPrimHost;
             has_host = true;
-        } else if (pr.kind == NNBVH_PRIM_TRIANGLE || pr.kind == NNBVH_PRIM_BILINEAR_PATCH) {
-            const int nv = pr.kind == NNBVH_PRIM_TRIANGLE ? 3 : 4;
+        } else if (is_triangle_kind(pr.kind) || pr.kind == NNBVH_PRIM_BILINEAR_PATCH) {
+            const int nv = is_triangle_kind(pr.kind) ? 3 : 4;
+            if (pr.kind == NNBVH_PRIM_ALPHA_TRIANGLE || pr.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED) {
+                // the alpha value rides in v[3] (bit pattern) and goes to slot 2's w, as in the BVH scenes;
+                // a re-trace that hits voids the ray like a host primitive, and the test needs the ray
+                // direction: such scenes run the PATCH instances
+                flags |= kPrimAlpha | (pr.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED ? kPrimFlipN : 0u);
+                has_host = true;
+                has_patch = true;
+            }
             for (int j = 0; j < nv; ++j) {
                 if (pr.v[j] < 0 || pr.v[j] >= n_verts) {
                     set_error("kd_scene_create: vertex index out of range");
@@ -572,13 +601,14 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
                 std::memcpy(&s[4 * j], verts + 3 * (size_t)pr.v[j], 12);
             }
             std::memcpy(&s[3], &pr.id, 4);
+            if (flags & kPrimAlpha) std::memcpy(&s[11], &pr.v[3], 4);
             if (nv == 4) {
                 flags |= kPrimPatch;
                 has_patch = true;
             }
             else if (kd_triangle_is_degenerate(&s[0], &s[4], &s[8])) flags |= kPrimDegenerate;
         } else {
-            set_error("kd_scene_create: unsupported primitive kind (triangles, patches, host primitives)");
+            set_error("kd_scene_create: unsupported primitive kind (triangles, alpha-tested triangles, patches, host primitives)");
             return nullptr;
         }
         std::memcpy(&s[7], &flags, 4);

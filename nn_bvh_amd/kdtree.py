@@ -113,7 +113,7 @@ def prim_bounds_of(prims, verts):
     """Per-primitive bounds (Triangle::Bounds / BilinearPatch::Bounds: min / max over the vertices)."""
     prims = np.asarray(prims)
     v = np.asarray(verts, np.float32)[prims["v"]]
-    tri = (prims["kind"] == 0)[:, None, None]
+    tri = np.isin(prims["kind"], (0, 4, 5))[:, None, None]  # triangles and alpha-tested triangles
     lo = np.where(tri, v[:, :3].min(1, keepdims=True), v.min(1, keepdims=True))[:, 0]
     hi = np.where(tri, v[:, :3].max(1, keepdims=True), v.max(1, keepdims=True))[:, 0]
     return lo.astype(np.float32), hi.astype(np.float32)

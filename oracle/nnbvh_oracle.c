@@ -1710,8 +1710,14 @@ static void kd_one(const orc_kd_node *nodes, const int32_t *prim_indices, const 
                         host = 1;
                         continue;
                     }
-                    ++tests;
-                    if (prim_test(p, verts, o, d, rayTMax, r)) {
+                    int primHit; /* GeometricPrimitive with a constant alpha: cpu/primitive.cpp:57-70, 79-81 */
+                    if (p->kind == 4 || p->kind == 5) {
+                        primHit = alpha_intersect(p, verts, o, d, rayTMax, r, &tests, &host);
+                    } else {
+                        ++tests;
+                        primHit = prim_test(p, verts, o, d, rayTMax, r);
+                    }
+                    if (primHit) {
                         if (closest) {
                             hit->prim = p->id;
                             hit->b0 = r[0];

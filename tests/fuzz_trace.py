@@ -201,7 +201,7 @@ def main():
             agg.set_option("stack_window", int(rng.choice([4, 16])))
         rays = draw_rays(rng, verts, prims, args.rays)
         bad, exp = compare(agg, tree, verts, rays)
-        if args.kd and not np.isin(prims["kind"], (4, 5)).any():  # the kd kernels take triangles, patches, host primitives
+        if args.kd:
             kbad = compare_kd(verts, prims, rays, max_prims=int(rng.choice([1, 4])))
             if kbad:
                 print(f"KD MISMATCH seed {seed}: {len(kbad)} rays, first {kbad[:5]}", flush=True)

@@ -208,6 +208,20 @@ def test_device_kd_traversal_equals_oracle_on_soups(max_prims):
 
 
 @pytest.mark.gpu
+def test_device_kd_traversal_with_alpha_tested_triangles():
+    """GeometricPrimitives with a constant alpha inside a KdTreeAggregate (kinds 4 / 5): the same stochastic
+    test and re-trace as in the BVH kernels, once per leaf the primitive overlaps."""
+    from test_alpha import alpha_scene
+    verts, prims, alpha, kinds = alpha_scene(6, 2500)
+    tree = build_kd_tree(prims, verts, max_prims=2)
+    rays = np.concatenate([scene.random_rays(30000, verts.min(0) - 1, verts.max(0) + 1, 21),
+                           scene.random_rays(8000, verts.min(0), verts.max(0), 22, tmax=0.6)])
+    hits = _gpu_parity(prims, verts, tree, rays)
+    mid = (alpha > 0) & (alpha < 1) & (kinds != 0)
+    assert ((hits["prim"] >= 0) & mid[np.maximum(hits["prim"], 0)]).sum() > 500
+
+
+@pytest.mark.gpu
 def test_device_kd_traversal_mesh_host_prims_and_deep_stack():
     # connected mesh: shared edges / vertices, ties
     verts, prims = ss.grid_mesh(64, 3)
