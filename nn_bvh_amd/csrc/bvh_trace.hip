@@ -12,11 +12,12 @@
 //     terminated are refilled in place (ballot + mbcnt compaction of the idle lanes), so
 //     SIMD slots stay occupied although rays visit 1..400 nodes each;
 //   * one 64-B "both children" record per interior node (nnbvh_internal.h) halves the
-//     length of the dependent-load chain of the reference's 32-B node walk; the far child
-//     is pushed WITH its slab entry distance, so the deferred box test the reference
-//     performs when it pops the node (`tMin < tMax` with the then-current tMax) needs no
-//     memory access at all and still gives the identical boolean;
-//   * the per-lane traversal stack is a short ring window in LDS ([entry][lane], bank-
+//     length of the dependent-load chain of the reference's 32-B node walk; a child box's
+//     whole slab test is carried by ONE float, its entry distance or +inf (trace_math.h
+//     slab_entry_key), and the far child is pushed WITH it, so the deferred box test the
+//     reference performs when it pops the node (`tMin < tMax` with the then-current tMax)
+//     needs no memory access at all and still gives the identical boolean;
+//   * the per-lane traversal stack is a short ring window in LDS ([entry][word][lane], bank-
 //     conflict-free) that spills its oldest entry to a coalesced HBM scratch array only
 //     when a ray's pending-node list outgrows the window;
 //   * fp32 arithmetic is emitted with -ffp-contract=off; __builtin_fmaf appears exactly
@@ -73,9 +74,13 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 // returns to the outer leaf when the child is exhausted.  Compiled separately so that
 // single-level scenes pay nothing for it.
 //
-// PATCH = 0: the scene holds no bilinear patches and no instances, so nothing ever reads the ray
-// direction after the ray is fetched; it is not parked in LDS (3 fields = 3 KiB per block less:
-// 22 KiB, which lets a seventh block share the CU's 160 KiB).
+// INST = 2: ... with AnimatedPrimitives among the instances (the interpolation of the transform costs 60
+// VGPRs; scenes whose instances are all static run INST = 1).
+//
+// PATCH = 0 ("lean"): the scene holds no bilinear patches, no instances and no host-only primitives, so
+// nothing ever reads the ray direction after the ray is fetched: no patch test, no direction / ray
+// index / host flag in LDS (20 KiB per block = 8 blocks per CU), <= 64 VGPRs = 8 wavefronts per SIMD,
+// records and slots through 32-bit offsets from a scalar base, one primitive step per decision.
 // ALPHA = 1: the scene holds alpha-tested triangles (kPrimAlpha, cpu/primitive.cpp:57-70); compiled
 // separately so that other scenes pay nothing for the hash and the re-trace.
 template <int MODE, int W, int INST, int PATCH, int ALPHA = 0>
