@@ -91,6 +91,9 @@ def parse_args(argv=None):
     ap.add_argument("--serial", action="store_true",
                     help="trace the three batches of a step as three launches (round-1 behaviour) instead "
                          "of one nnbvh_trace_batches_device call = ONE launch over all three")
+    ap.add_argument("--ray-order", default="pixel", choices=["pixel", "sample"],
+                    help="order of a step's rays: pixel = the spp samples of a pixel adjacent (each XCD's share of "
+                         "the batch is then a region of the image), sample = spp whole-image passes concatenated")
     ap.add_argument("--overlapped", action="store_true",
                     help="also time the step with the three batches as concurrent launches on the "
                          "library's internal streams (fused_batches off)")
@@ -272,8 +275,14 @@ def main():
     t_gen = time.time()
     sets = []
     for k in range(max(1, args.sample_sets)):
-        primary = np.concatenate([scene.camera_rays(cam_name, seed=1, sample=k * passes + s_idx, subset=mine)
-                                  for s_idx in range(passes)])
+        per_pass = [scene.camera_rays(cam_name, seed=1, sample=k * passes + s_idx, subset=mine)
+                    for s_idx in range(passes)]
+        if args.ray_order == "pixel":  # ray r = sample r % passes of slot r // passes
+            primary = np.stack(per_pass, 1).reshape(-1)
+            sample_slot = (np.arange(len(primary)) % passes) * n_slots + np.arange(len(primary)) // passes
+        else:                          # ray r = sample r // n_slots of slot r % n_slots
+            primary = np.concatenate(per_pass)
+            sample_slot = np.arange(len(primary))
         n_primary = len(primary)
         d_primary = dev(primary)
         d_hits = torch.empty(n_primary * 32, dtype=torch.uint8, device=cdev)
@@ -297,7 +306,8 @@ def main():
             "d_occ": torch.empty(len(shadow), dtype=torch.uint8, device=cdev),
             # ShadowRayWorkItem payload (workitems.soa:77-83): Ld, r_u, r_l per shadow ray, the pixel
             # sample it belongs to; PixelSampleState::L per pixel sample (SampledSpectrum = 4 floats)
-            "d_pix": torch.from_numpy(np.nonzero(hits["prim"] >= 0)[0].astype(np.int32)).to(cdev),
+            # (index into L, which stays [pass][slot] whatever the order of the rays)
+            "d_pix": torch.from_numpy(sample_slot[hits["prim"] >= 0].astype(np.int32)).to(cdev),
             "d_Ld": torch.rand((len(shadow), 4), generator=gen, device=cdev) * 2.0,
             "d_ru": torch.rand((len(shadow), 4), generator=gen, device=cdev) + 0.5,
             "d_rl": torch.rand((len(shadow), 4), generator=gen, device=cdev) + 0.5,
@@ -563,6 +573,8 @@ def main():
                             f"sample sets; BASELINE's 1024 spp = {1024 // max(1, total_spp)} such passes, "
                             f"extrapolated per SURVEY §8d (>= 64 M rays per class timed), not traced",
                 "spp_per_step": args.spp,
+                "ray_order": ("pixel-major: the spp samples of a pixel are adjacent in every batch"
+                              if args.ray_order == "pixel" else "sample-major: spp whole-image passes concatenated"),
                 "sample_sets": len(sets),
                 "geometry": source,
                 "tree": args.tree,
