@@ -91,9 +91,11 @@ def parse_args(argv=None):
     ap.add_argument("--serial", action="store_true",
                     help="trace the three batches of a step as three launches (round-1 behaviour) instead "
                          "of one nnbvh_trace_batches_device call = ONE launch over all three")
-    ap.add_argument("--ray-order", default="pixel", choices=["pixel", "sample"],
-                    help="order of a step's rays: pixel = the spp samples of a pixel adjacent (each XCD's share of "
-                         "the batch is then a region of the image), sample = spp whole-image passes concatenated")
+    ap.add_argument("--ray-order", default="tile", choices=["tile", "pixel", "sample"],
+                    help="order of a step's rays: pixel = the spp samples of a pixel adjacent, pixels in scanline "
+                         "order (each XCD's share of the batch is then a region of the image); tile = the same with "
+                         "the pixels in 4x4 tiles (a wavefront's 64 rays = 8 pixels of a 4x2 block); sample = spp "
+                         "whole-image passes concatenated")
     ap.add_argument("--overlapped", action="store_true",
                     help="also time the step with the three batches as concurrent launches on the "
                          "library's internal streams (fused_batches off)")
@@ -262,6 +264,8 @@ def main():
     xres, yres = scene.CAMERAS[cam_name][4], scene.CAMERAS[cam_name][5]
     _, px, py = scene.camera_rays(cam_name, seed=1, sample=0, return_pixels=True)
     index_lists = [shard.shard_indices(px, py, xres, world, r) for r in range(world)]
+    if args.ray_order == "tile":  # every rank's pixels in 4x4 tiles (row order of tiles, scanlines inside)
+        index_lists = [ix[np.lexsort((px[ix], py[ix], px[ix] // 4, py[ix] // 4))] for ix in index_lists]
     mine = index_lists[rank]
     n_slots = len(mine)                     # pixel slots of this rank = film pixels it owns
     passes = world * args.spp               # samples per pixel and step
@@ -277,7 +281,7 @@ def main():
     for k in range(max(1, args.sample_sets)):
         per_pass = [scene.camera_rays(cam_name, seed=1, sample=k * passes + s_idx, subset=mine)
                     for s_idx in range(passes)]
-        if args.ray_order == "pixel":  # ray r = sample r % passes of slot r // passes
+        if args.ray_order != "sample":  # ray r = sample r % passes of slot r // passes
             primary = np.stack(per_pass, 1).reshape(-1)
             sample_slot = (np.arange(len(primary)) % passes) * n_slots + np.arange(len(primary)) // passes
         else:                          # ray r = sample r // n_slots of slot r % n_slots
@@ -573,8 +577,11 @@ def main():
                             f"sample sets; BASELINE's 1024 spp = {1024 // max(1, total_spp)} such passes, "
                             f"extrapolated per SURVEY §8d (>= 64 M rays per class timed), not traced",
                 "spp_per_step": args.spp,
-                "ray_order": ("pixel-major: the spp samples of a pixel are adjacent in every batch"
-                              if args.ray_order == "pixel" else "sample-major: spp whole-image passes concatenated"),
+                "ray_order": {"tile": "pixel-major, pixels in 4x4 tiles: the spp samples of a pixel are adjacent in every "
+                                      "batch, a wavefront's 64 rays cover a 4x2 block of pixels",
+                              "pixel": "pixel-major: the spp samples of a pixel are adjacent in every batch, pixels in "
+                                       "scanline order",
+                              "sample": "sample-major: spp whole-image passes concatenated"}[args.ray_order],
                 "sample_sets": len(sets),
                 "geometry": source,
                 "tree": args.tree,

@@ -20,8 +20,27 @@ def main():
     spp = 8
     passes = [scene.camera_rays("crown", seed=1, sample=s) for s in range(spp)]
     npix = len(passes[0])
+    _, px, py = scene.camera_rays("crown", seed=1, sample=0, return_pixels=True)
+    pm = np.stack(passes, 1)  # [pixel][sample]
+
+    def tiled(t):
+        order = np.lexsort((px, py, px // t, py // t))  # tiles of t x t pixels in row order, scanlines inside
+        return pm[order].reshape(-1)
+
+    def morton():
+        def spread(v):
+            v = v.astype(np.uint64)
+            v = (v | (v << 8)) & 0x00FF00FF
+            v = (v | (v << 4)) & 0x0F0F0F0F
+            v = (v | (v << 2)) & 0x33333333
+            v = (v | (v << 1)) & 0x55555555
+            return v
+        return pm[np.argsort(spread(px) | (spread(py) << 1), kind="stable")].reshape(-1)
+
     orders = {"sample-major (8 passes concatenated)": np.concatenate(passes),
-              "pixel-major (8 samples of a pixel adjacent)": np.stack(passes, 1).reshape(-1)}
+              "pixel-major (8 samples of a pixel adjacent)": pm.reshape(-1),
+              "pixel-major, 16x16 tiles": tiled(16), "pixel-major, 4x4 tiles": tiled(4),
+              "pixel-major, Morton order of the pixels": morton()}
     stream = torch.cuda.current_stream().cuda_stream
     for label, primary in orders.items():
         hits = agg.Intersect(primary)
