@@ -27,7 +27,10 @@ def main():
     verts, tris, source = scene.load_scene("crown")
     tree = build_tree(make_prims(tris), verts)
     agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
-    primary = np.concatenate([scene.camera_rays("crown", seed=1, sample=s) for s in range(args.spp)])
+    # the bench's ray order: pixel-major, the pixels in 4x4 tiles
+    _, px, py = scene.camera_rays("crown", seed=1, sample=0, return_pixels=True)
+    tiles = np.lexsort((px, py, px // 4, py // 4))
+    primary = np.stack([scene.camera_rays("crown", seed=1, sample=s) for s in range(args.spp)], 1)[tiles].reshape(-1)
     hits = agg.Intersect(primary)
     bounce = scene.bounce_rays(primary, hits, verts, tris, seed=2)
     shadow = scene.shadow_rays_to_quads(primary, hits, verts, tris, scene.CROWN_LIGHT_QUADS, seed=3)
