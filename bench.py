@@ -5,8 +5,9 @@ One "step" = one wavefront pass of --spp samples per pixel (default 8, each samp
 jitter stream) over the crown film through the hot path, all ray batches already resident in
 HBM, one launch per ray class:
     closest-hit  over spp x 1000x1400 primary rays   (BVHAggregate::Intersect)
-    closest-hit  over the diffuse-bounce rays of those hits
-    any-hit      over the shadow rays of those hits  (BVHAggregate::IntersectP, tMax = 1-1e-4)
+    closest-hit  over the diffuse-bounce rays of those hits            (bounce 1)
+    closest-hit  over the diffuse-bounce rays of the bounce-1 hits     (bounce 2)
+    any-hit      over the shadow rays of the primary hits  (BVHAggregate::IntersectP, tMax = 1-1e-4)
     RecordShadowRayResult -> L per pixel sample, UpdateFilm / RGBFilm::AddSample -> the film's
     4 doubles per pixel (film.h:239-255, 302-307)
 value = rays traced by all ranks / wall time of K steps (max over ranks).  Consecutive steps
@@ -86,8 +87,12 @@ def parse_args(argv=None):
                          "*_gpu = the same sah / hlbvh tree built and baked on the device, kd = the "
                          "reference's KdTreeAggregate (aggregates.cpp:746-1161) on its own traversal kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--wavefront", action="store_true",
-                    help="also time the step through the wavefront-queue entry points")
+    ap.add_argument("--wavefront", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-wavefront", action="store_true",
+                    help="skip the dependent form of the step (wavefront-queue entry points, one launch per "
+                         "queue), reported as dependent_step_ms")
+    ap.add_argument("--no-order-probe", action="store_true",
+                    help="skip timing the step's traces with the rays in the reference integrator's sample-major order")
     ap.add_argument("--serial", action="store_true",
                     help="trace the three batches of a step as three launches (round-1 behaviour) instead "
                          "of one nnbvh_trace_batches_device call = ONE launch over all three")
@@ -145,11 +150,11 @@ def dry_run(args, rank, world):
     return 0
 
 
-def profile_counters(prefix="trace_kernel<0"):
-    """VALU-issue figures of the dominant kernel (name prefix) from the newest committed rocprofv3 PMC
-    summary that holds it (profiles/r*_final*/summary.json; collected as MI355X_MICROARCH.md
-    prescribes, separate --pmc passes of this same command).  None if no summary is present."""
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final*", "summary.json")))
+def profile_counters(prefix, pattern="r*_final*"):
+    """PMC figures of the dominant kernel (name prefix) from the newest committed rocprofv3 summary that holds
+    it (profiles/<pattern>/summary.json; collected as MI355X_MICROARCH.md prescribes: separate --pmc passes of
+    this same command, tools/profile_bench.sh).  None if no summary is present."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern, "summary.json")))
     for path in reversed(paths):
         try:
             summ = json.load(open(path))
@@ -162,11 +167,13 @@ def profile_counters(prefix="trace_kernel<0"):
                 "spp": summ.get("spp"),
                 "kernel": name,
                 "avg_launch_ms": round(float(ks["AverageNs"]) / 1e6, 4),
+                "valu_insts_per_launch": c["SQ_INSTS_VALU"],
                 # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (tools/halfwave_probe.hip)
                 "frac": round(c["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cycles), 4),
                 "lanes_per_valu": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"], 2),
                 "salu_per_valu": round(c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"], 3),
                 "wait_frac_of_wave_cycles": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+                "l2_hit": round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3),
                 "hbm_bytes_per_launch": round(c["TCC_EA0_RDREQ_sum"] * 128 - c.get("TCC_EA0_RDREQ_32B_sum", 0) * 96
                                               - c.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 + c["WRITE_SIZE"] * 1024),
             }
@@ -294,6 +301,13 @@ def main():
         torch.cuda.synchronize()
         hits = d_hits.cpu().numpy().view(HIT_DTYPE)
         bounce = scene.bounce_rays(primary, hits, verts, tris, seed=[2, rank, k])
+        # bounce 2: the diffuse bounce of the bounce-1 hits (the incoherent regime)
+        d_bounce = dev(bounce)
+        d_bhits = torch.empty(len(bounce) * 32, dtype=torch.uint8, device=cdev)
+        agg.intersect_device(d_bounce.data_ptr(), d_bhits.data_ptr(), len(bounce), stream)
+        torch.cuda.synchronize()
+        bhits0 = d_bhits.cpu().numpy().view(HIT_DTYPE)
+        bounce2 = scene.bounce_rays(bounce, bhits0, verts, tris, seed=[4, rank, k])
         if args.scene == "crown":  # towards the scene's six area-light quads (crown.pbrt:26-102)
             shadow = scene.shadow_rays_to_quads(primary, hits, verts, tris, scene.CROWN_LIGHT_QUADS,
                                                 seed=[3, rank, k])
@@ -303,10 +317,12 @@ def main():
         gen = torch.Generator(device=cdev).manual_seed(100 + 10 * rank + k)
         st = {
             "primary": primary if k == 0 else None, "bounce": bounce if k == 0 else None,
+            "bounce2": bounce2 if k == 0 else None,
             "shadow": shadow if k == 0 else None, "hits": hits if k == 0 else None,
-            "n_primary": n_primary, "n_bounce": len(bounce), "n_shadow": len(shadow),
-            "d_primary": d_primary, "d_hits": d_hits, "d_bounce": dev(bounce), "d_shadow": dev(shadow),
-            "d_bhits": torch.empty(len(bounce) * 32, dtype=torch.uint8, device=cdev),
+            "n_primary": n_primary, "n_bounce": len(bounce), "n_bounce2": len(bounce2), "n_shadow": len(shadow),
+            "d_primary": d_primary, "d_hits": d_hits, "d_bounce": d_bounce, "d_shadow": dev(shadow),
+            "d_bhits": d_bhits, "d_bounce2": dev(bounce2),
+            "d_b2hits": torch.empty(len(bounce2) * 32, dtype=torch.uint8, device=cdev),
             "d_occ": torch.empty(len(shadow), dtype=torch.uint8, device=cdev),
             # ShadowRayWorkItem payload (workitems.soa:77-83): Ld, r_u, r_l per shadow ray, the pixel
             # sample it belongs to; PixelSampleState::L per pixel sample (SampledSpectrum = 4 floats)
@@ -320,7 +336,7 @@ def main():
         }
         sets.append(st)
     s0 = sets[0]
-    rays_per_step = s0["n_primary"] + s0["n_bounce"] + s0["n_shadow"]
+    rays_per_step = s0["n_primary"] + s0["n_bounce"] + s0["n_bounce2"] + s0["n_shadow"]
     if rank == 0:
         log(f"[bench] {len(sets)} sample sets x {passes} samples generated in {time.time() - t_gen:.1f}s; "
             f"{rays_per_step} rays/step/GPU")
@@ -348,14 +364,19 @@ def main():
 
     fused = not args.serial and kd is None
 
+    def batches_of(st):
+        return [("closest", st["d_primary"].data_ptr(), st["n_primary"], st["d_hits"].data_ptr()),
+                ("closest", st["d_bounce"].data_ptr(), st["n_bounce"], st["d_bhits"].data_ptr()),
+                ("closest", st["d_bounce2"].data_ptr(), st["n_bounce2"], st["d_b2hits"].data_ptr()),
+                ("any", st["d_shadow"].data_ptr(), st["n_shadow"], st["d_occ"].data_ptr())]
+
     def trace_stage(st):
-        if fused:  # one launch: the wavefronts drain primary, bounce and shadow rays one batch after the other
-            agg.trace_batches_device([("closest", st["d_primary"].data_ptr(), st["n_primary"], st["d_hits"].data_ptr()),
-                                      ("closest", st["d_bounce"].data_ptr(), st["n_bounce"], st["d_bhits"].data_ptr()),
-                                      ("any", st["d_shadow"].data_ptr(), st["n_shadow"], st["d_occ"].data_ptr())], stream)
+        if fused:  # one launch: the wavefronts drain primary, bounce-1, bounce-2 and shadow rays one batch after the other
+            agg.trace_batches_device(batches_of(st), stream)
             return
         agg.intersect_device(st["d_primary"].data_ptr(), st["d_hits"].data_ptr(), st["n_primary"], stream)
         agg.intersect_device(st["d_bounce"].data_ptr(), st["d_bhits"].data_ptr(), st["n_bounce"], stream)
+        agg.intersect_device(st["d_bounce2"].data_ptr(), st["d_b2hits"].data_ptr(), st["n_bounce2"], stream)
         agg.intersect_p_device(st["d_shadow"].data_ptr(), st["d_occ"].data_ptr(), st["n_shadow"], stream=stream)
 
     def step(i):
@@ -381,7 +402,7 @@ def main():
     elapsed = max_over_ranks(elapsed)
     # every set has its own bounce / shadow counts: rays actually traced in the K steps
     def rays_of(st):
-        return st["n_primary"] + st["n_bounce"] + st["n_shadow"]
+        return st["n_primary"] + st["n_bounce"] + st["n_bounce2"] + st["n_shadow"]
     rays_timed = float(sum(rays_of(sets[i % len(sets)]) for i in range(args.steps)))
     if world > 1:
         tot = torch.tensor([rays_timed], dtype=torch.float64, device=coll_dev)
@@ -434,17 +455,20 @@ def main():
         return float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     reps = max(3, min(args.steps, 10))
-    n_primary, n_bounce, n_shadow = s0["n_primary"], s0["n_bounce"], s0["n_shadow"]
+    n_primary, n_bounce, n_bounce2, n_shadow = s0["n_primary"], s0["n_bounce"], s0["n_bounce2"], s0["n_shadow"]
     ms_primary = time_kernel(lambda: agg.intersect_device(s0["d_primary"].data_ptr(), s0["d_hits"].data_ptr(),
                                                           n_primary, stream), reps)
     ms_bounce = time_kernel(lambda: agg.intersect_device(s0["d_bounce"].data_ptr(), s0["d_bhits"].data_ptr(),
                                                          n_bounce, stream), reps)
+    ms_bounce2 = time_kernel(lambda: agg.intersect_device(s0["d_bounce2"].data_ptr(), s0["d_b2hits"].data_ptr(),
+                                                          n_bounce2, stream), reps)
     ms_shadow = time_kernel(lambda: agg.intersect_p_device(s0["d_shadow"].data_ptr(), s0["d_occ"].data_ptr(),
                                                            n_shadow, stream=stream), reps)
     ms_film = time_kernel(lambda: film_stage(s0), reps)
     hits = s0["hits"]
-    primary, bounce, shadow = s0["primary"], s0["bounce"], s0["shadow"]
+    primary, bounce, bounce2, shadow = s0["primary"], s0["bounce"], s0["bounce2"], s0["shadow"]
     bhits = s0["d_bhits"].cpu().numpy().view(HIT_DTYPE)
+    b2hits = s0["d_b2hits"].cpu().numpy().view(HIT_DTYPE)
 
     # algorithmic bytes: 32 in + 32*V + 48*T + 32 out per closest-hit ray (a
     # KdTreeNode is 8 B, and a leaf primitive costs its 4-B index besides the 48 B of the triangle)
@@ -453,11 +477,11 @@ def main():
     def alg_bytes(h):
         return 64.0 * len(h) + node_bytes * h["nodes_visited"].sum(dtype=np.int64) + \
             prim_bytes * h["prim_tests"].sum(dtype=np.int64)
-    bytes_closest = alg_bytes(hits) + alg_bytes(bhits)          # both launches of the kernel
-    ms_closest = ms_primary + ms_bounce
+    bytes_closest = alg_bytes(hits) + alg_bytes(bhits) + alg_bytes(b2hits)   # the three launches of the kernel
+    ms_closest = ms_primary + ms_bounce + ms_bounce2
     achieved = bytes_closest / (ms_closest * 1e-3) / 1e9         # GB/s over the kernel's launches
     roof_kernel = "kd_trace_kernel<closest>" if kd is not None else "trace_kernel<closest>"
-    roof_bytes_per_launch, roof_ms = bytes_closest / 2, ms_closest / 2
+    roof_bytes_per_launch, roof_ms = bytes_closest / 3, ms_closest / 3
     if fused:
         # the dominant kernel is the one launch of a step: trace_kernel<3> over all three batches.  Its
         # algorithmic bytes add the shadow rays' 36 + 32 V + 48 T (V, T from a counting any-hit launch)
@@ -469,16 +493,14 @@ def main():
         bytes_shadow = 36.0 * n_shadow + node_bytes * float(d_v.sum(dtype=torch.int64).item()) + \
             prim_bytes * float(d_t.sum(dtype=torch.int64).item())
         ms_fused = time_kernel(lambda: trace_stage(s0), reps)
-        roof_kernel = "trace_kernel<3> (one launch: primary + bounce closest-hit, shadow any-hit)"
+        roof_kernel = "trace_kernel<3> (one launch: primary + bounce-1 + bounce-2 closest-hit, shadow any-hit)"
         roof_bytes_per_launch, roof_ms = bytes_closest + bytes_shadow, ms_fused
         achieved = roof_bytes_per_launch / (roof_ms * 1e-3) / 1e9
 
     # ---- the same step through nnbvh_trace_batches_device: the three batches run concurrently
     # on the library's internal streams, so each launch's drain overlaps the others' work.
     def step_overlapped():
-        agg.trace_batches_device([("closest", s0["d_primary"].data_ptr(), n_primary, s0["d_hits"].data_ptr()),
-                                  ("closest", s0["d_bounce"].data_ptr(), n_bounce, s0["d_bhits"].data_ptr()),
-                                  ("any", s0["d_shadow"].data_ptr(), n_shadow, s0["d_occ"].data_ptr())], stream)
+        agg.trace_batches_device(batches_of(s0), stream)
 
     overlapped_s = None
     if args.overlapped:
@@ -492,28 +514,31 @@ def main():
         overlapped_s = max_over_ranks(time.perf_counter() - t1)
         agg.set_option("fused_batches", 1)
 
-    # ---- the same step through the wavefront-queue entry points (SOA ray queues with
-    # device-side sizes in, index queues and pixel radiance out): opt-in, reported next to `value`
+    # ---- the DEPENDENT form of the step: the same batches through the wavefront-queue entry points (SOA ray
+    # queues with device-side sizes in, index queues and pixel radiance out), one launch per queue as an
+    # integrator whose bounce rays depend on the previous hits must issue them.  Reported next to `value`
+    # (dependent_step_ms): the headline's one launch per step needs batches that are independent.
     wavefront_s = wavefront_intr_s = None
-    if args.wavefront:
+    if not args.no_wavefront and kd is None:
         from nn_bvh_amd.wavefront import RayQueue, WavefrontAggregate, WorkQueue
         from nn_bvh_amd._lib import CLOSEST_QUEUES
         wf = WavefrontAggregate(agg, np.zeros(len(tris), np.uint8))
         q_primary, q_bounce = RayQueue.from_records(primary, cdev), RayQueue.from_records(bounce, cdev)
+        q_bounce2 = RayQueue.from_records(bounce2, cdev)
         q_shadow = RayQueue.from_records(shadow, cdev, shadow=True)
         outq = {k: WorkQueue(n_primary, cdev) for k in CLOSEST_QUEUES}
         pix = torch.arange(n_shadow, dtype=torch.int32, device=cdev)
         Lw = torch.zeros((n_shadow, 4), dtype=torch.float32, device=cdev)
         d_hits2 = s0["d_hits"].view(-1, 32)
         d_bhits2 = s0["d_bhits"].view(-1, 32)
+        d_b2hits2 = s0["d_b2hits"].view(-1, 32)
 
         def step_wavefront():
-            for q in outq.values():
-                q.Reset()
-            wf.IntersectClosest(n_primary, q_primary, hits=d_hits2, **outq)
-            for q in outq.values():
-                q.Reset()
-            wf.IntersectClosest(n_bounce, q_bounce, hits=d_bhits2, **outq)
+            for n_q, q_in, h_out in ((n_primary, q_primary, d_hits2), (n_bounce, q_bounce, d_bhits2),
+                                     (n_bounce2, q_bounce2, d_b2hits2)):
+                for q in outq.values():
+                    q.Reset()
+                wf.IntersectClosest(n_q, q_in, hits=h_out, **outq)
             wf.IntersectShadow(n_shadow, q_shadow, s0["d_Ld"], s0["d_ru"], s0["d_rl"], pix, Lw)
 
         step_wavefront()
@@ -523,7 +548,7 @@ def main():
             step_wavefront()
         barrier()
         wavefront_s = max_over_ranks(time.perf_counter() - t1)
-        # ... and with the hit -> SurfaceInteraction post-pass of both closest-hit stages
+        # ... and with the hit -> SurfaceInteraction post-pass of the closest-hit stages
         # (Triangle::InteractionFromIntersection, which the reference's Intersect runs per hit)
         from nn_bvh_amd.interaction import ShadingMesh
         smesh = ShadingMesh(verts, tris, device=local_rank)
@@ -531,10 +556,9 @@ def main():
 
         def step_wavefront_intr():
             step_wavefront()
-            smesh.interactions_device(d_hits2.data_ptr(), n_primary, d_intr.data_ptr(), ray_queue=q_primary,
-                                      stream=stream)
-            smesh.interactions_device(d_bhits2.data_ptr(), n_bounce, d_intr.data_ptr(), ray_queue=q_bounce,
-                                      stream=stream)
+            for h_out, n_q, q_in in ((d_hits2, n_primary, q_primary), (d_bhits2, n_bounce, q_bounce),
+                                     (d_b2hits2, n_bounce2, q_bounce2)):
+                smesh.interactions_device(h_out.data_ptr(), n_q, d_intr.data_ptr(), ray_queue=q_in, stream=stream)
 
         step_wavefront_intr()
         barrier()
@@ -543,14 +567,54 @@ def main():
             step_wavefront_intr()
         barrier()
         wavefront_intr_s = max_over_ranks(time.perf_counter() - t1)
+        del q_primary, q_bounce, q_bounce2, q_shadow, outq, d_intr, Lw, pix
+
+    # ---- the step's traces with the SAME rays in the order the reference's wavefront integrator forms them:
+    # one sample of every pixel per pass, the passes one after the other (wavefront/integrator.cpp:231-236,
+    # 336-368), instead of this bench's pixel-major order.  The order decides nothing but which lane traces
+    # which ray; it is a caller-side choice, so both figures are printed.
+    order_probe = None
+    if not args.no_order_probe and args.ray_order != "sample" and fused and rank == 0 and world == 1:
+        def sample_major(idx_in_parent, n_parent_slots):
+            """order of a compacted batch whose ray j descends from pixel-major ray idx_in_parent[j]"""
+            key = (idx_in_parent % passes).astype(np.int64) * n_parent_slots + idx_in_parent // passes
+            return np.argsort(key, kind="stable")
+        root_of_primary = np.arange(n_primary)
+        hit_idx = np.nonzero(hits["prim"] >= 0)[0]                     # bounce-1 / shadow ray j <- primary hit_idx[j]
+        root_of_bounce = root_of_primary[hit_idx]
+        root_of_bounce2 = root_of_bounce[np.nonzero(bhits["prim"] >= 0)[0]]
+        perms = [sample_major(r, n_slots) for r in (root_of_primary, root_of_bounce, root_of_bounce2, root_of_bounce)]
+        d_alt = [dev(a[pm]) for a, pm in zip((primary, bounce, bounce2, shadow), perms)]
+        alt = [("closest", d_alt[0].data_ptr(), n_primary, s0["d_hits"].data_ptr()),
+               ("closest", d_alt[1].data_ptr(), n_bounce, s0["d_bhits"].data_ptr()),
+               ("closest", d_alt[2].data_ptr(), n_bounce2, s0["d_b2hits"].data_ptr()),
+               ("any", d_alt[3].data_ptr(), n_shadow, s0["d_occ"].data_ptr())]
+        ms_alt = time_kernel(lambda: agg.trace_batches_device(alt, stream), reps)
+        ms_own = time_kernel(lambda: trace_stage(s0), reps)
+        order_probe = {
+            "this_order_trace_ms": round(ms_own, 4), "this_order_mrays": round(rays_per_step / ms_own / 1e3, 1),
+            "reference_order_trace_ms": round(ms_alt, 4),
+            "reference_order_mrays": round(rays_per_step / ms_alt / 1e3, 1),
+            "how": "the same four batches of sample set 0 (traces only, one launch), rays permuted into the order of "
+                   "the reference's wavefront integrator: one sample of every pixel per pass, passes concatenated "
+                   "(wavefront/integrator.cpp:231-236, 336-368); `value` uses --ray-order " + args.ray_order +
+                   ", a caller-side ordering the reference does not perform",
+        }
+        del d_alt
+        agg.trace_batches_device(batches_of(s0), stream)  # restore set 0's own results for the checks below
+        torch.cuda.synchronize()
 
     # What binds the kernel, from the committed rocprofv3 PMC passes of this same command
     # (profiles/; collected and corrected as MI355X_MICROARCH.md §HBM prescribes).  Only quoted when
     # the profile was taken at the same --spp on crown at N=1.
-    prof = profile_counters("trace_kernel<3" if fused else "trace_kernel<0")
-    if prof is not None and not (prof.get("spp") in (None, args.spp) and args.scene == "crown" and world == 1 and kd is None):
+    if kd is not None:
+        prof = profile_counters("kd_trace_kernel<0", "r*_kd_" + args.scene + "*")
+    else:
+        prof = profile_counters("trace_kernel<3" if fused else "trace_kernel<0")
+    if prof is not None and not (prof.get("spp") in (None, args.spp) and args.scene == "crown" and world == 1):
         prof = None
     traffic = prof["hbm_bytes_per_launch"] if prof else None
+    valu_peak = N_SIMD * SHADER_GHZ / 2.0  # G wave-instructions/s: one wave64 VALU instruction per SIMD-32 per 2 cycles
 
     result = None
     if rank == 0:
@@ -607,37 +671,43 @@ def main():
                        "sample in sample order (inside the timed step)",
             },
             "roofline": {
-                # the prescribed SURVEY §8d figure ("alg_hbm"): algorithmic bytes 64 + 32 V + 48 T per
-                # ray over the kernel's time against the HBM peak.  It prices every node re-read that
-                # L1/L2 serve, so it is NOT a physical bound and may exceed 1; `binding` names the
-                # limiter the counters show and `valu_issue` / `hbm_physical` quantify it.
-                "bound": "hbm",
-                "label": "alg_hbm",
+                # What binds the dominant kernel: the issue of vector instructions (wavefront-instructions
+                # per second against one wave64 instruction per SIMD-32 per 2 cycles), from the committed
+                # rocprofv3 PMC passes of this same command; `avg_launch_ms` is the live HIP-event time of this
+                # run.  The SURVEY §8d "algorithmic bytes" figure is kept under `alg_hbm`: it prices every node
+                # re-read that L1/L2 serve, so it is not a physical bound and may exceed 1.
+                "bound": "valu_issue" if prof else "valu_issue (no committed PMC profile for this configuration)",
                 "kernel": roof_kernel,
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "achieved": None if prof is None else round(prof["valu_insts_per_launch"] / (prof["avg_launch_ms"] * 1e-3) / 1e9, 1),
+                "peak": round(valu_peak, 1),
+                "unit": "G wave-instr/s",
+                "frac": None if prof is None else prof["frac"],
                 "traffic": traffic,
-                "alg_bytes_per_launch": round(roof_bytes_per_launch),
-                "alg_bytes_per_ray": round(bytes_closest / (len(hits) + len(bhits)), 1),
-                "mean_nodes_visited": round(float(hits["nodes_visited"].mean()), 2),
-                "mean_prim_tests": round(float(hits["prim_tests"].mean()), 2),
                 "avg_launch_ms": round(roof_ms, 4),
-                "binding": "valu_issue",
-                "valu_issue": None if prof is None else {
-                    "frac": prof["frac"], "lanes_per_valu": prof["lanes_per_valu"],
-                    "salu_per_valu": prof["salu_per_valu"],
-                    "wait_frac_of_wave_cycles": prof["wait_frac_of_wave_cycles"],
-                    "how": "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x launch cycles at 2.4 GHz); lanes = "
-                           "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)",
-                    "profile_avg_launch_ms": prof["avg_launch_ms"], "source": prof["source"],
-                },
+                "lanes_per_valu": None if prof is None else prof["lanes_per_valu"],
+                "salu_per_valu": None if prof is None else prof["salu_per_valu"],
+                "wait_frac_of_wave_cycles": None if prof is None else prof["wait_frac_of_wave_cycles"],
+                "l2_hit": None if prof is None else prof["l2_hit"],
+                "profile": None if prof is None else {"source": prof["source"], "avg_launch_ms": prof["avg_launch_ms"],
+                                                      "kernel": prof["kernel"]},
+                "how": "frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x launch cycles at 2.4 GHz); lanes = "
+                       "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64); traffic = TCC_EA0_RDREQ by size + "
+                       "WRITE_SIZE, bytes per launch",
                 "hbm_physical": None if prof is None else {
                     "achieved": round(prof["hbm_bytes_per_launch"] / (prof["avg_launch_ms"] * 1e-3) / 1e9, 1),
-                    "unit": "GB/s",
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(prof["hbm_bytes_per_launch"] / (prof["avg_launch_ms"] * 1e-3) / 1e9
                                   / HBM_PEAK_GBS, 4),
+                },
+                "alg_hbm": {
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "alg_bytes_per_launch": round(roof_bytes_per_launch),
+                    "alg_bytes_per_ray": round(bytes_closest / (len(hits) + len(bhits) + len(b2hits)), 1),
+                    "mean_nodes_visited": round(float(hits["nodes_visited"].mean()), 2),
+                    "mean_prim_tests": round(float(hits["prim_tests"].mean()), 2),
+                    "note": "SURVEY §8d: (64 + 32 V + 48 T) bytes per closest-hit ray, (36 + 32 V + 48 T) per any-hit ray, "
+                            "over the kernel's time; cache-served re-reads included, hence not a bound",
                 },
             },
         }

@@ -188,13 +188,14 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
         *error = "device bake: primitive stream exceeds 2^31 slots";
         return false;
     }
+    // ONE allocation: the interior records, then (256-B aligned) the primitive stream and 64 B of padding —
+    // the lean traversal kernels reach both with a 32-bit offset from one scalar base, and a lane that
+    // fetches a primitive through the interior record's 64-B load sequence may read one slot past it
     void *dWide = nullptr, *dStream = nullptr;
-    BK_CHECK(hipMalloc(&dWide, (size_t)std::max(nInterior, 1) * sizeof(WideNode)), "hipMalloc(nodes)");
-    if (hipMalloc(&dStream, (size_t)nSlots * 16) != hipSuccess) {
-        (void)hipFree(dWide);
-        *error = "device bake: hipMalloc(prims) failed";
-        return false;
-    }
+    const size_t wideBytes = (((size_t)std::max(nInterior, 1) * sizeof(WideNode)) + 255) & ~(size_t)255;
+    BK_CHECK(hipMalloc(&dWide, wideBytes + (size_t)nSlots * 16 + 64), "hipMalloc(nodes + primitives)");
+    dStream = (char *)dWide + wideBytes;
+    BK_CHECK(hipMemsetAsync((char *)dStream + (size_t)nSlots * 16, 0, 64, stream), "memset");
     hipLaunchKernelGGL(k_bake_stream, dim3(gp), dim3(kBk), 0, stream, dPrims, n_prims, dVerts, dSlotOf, dLeafLast,
                        (float4 *)dStream);
     hipLaunchKernelGGL(k_bake_wide, dim3(gn), dim3(kBk), 0, stream, dNodes, n_nodes, dOrd, dSlotOf, (float4 *)dWide);
@@ -205,7 +206,6 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) {
         (void)hipFree(dWide);
-        (void)hipFree(dStream);
         *error = std::string("device bake: ") + hipGetErrorString(e);
         return false;
     }

@@ -82,6 +82,7 @@ struct nnbvh_scene {
     int fused_batches = 1;  // nnbvh_trace_batches_device: one mode-3 launch where the batches allow it
     int int_repeat = 3;
     int prim_repeat = 2;
+    int prim_min = 8;  // only read by builds with -DNNBVH_MERGED=1  // merged trips of the lean kernels (bvh_trace.hip); 0 = separate interior / primitive trips
     int max_grid_threads = 0;
     double build_ms[1] = {0};  // device build time of nnbvh_scene_create_gpu_build
     std::mutex mu;
@@ -217,8 +218,7 @@ int nnbvh_device_count(void) {
 static nnbvh_scene *scene_from_baked(const BakedScene &b, int depth, int device) {
     hipDeviceProp_t prop;
     if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) {
-        (void)hipFree(b.d_wide);
-        (void)hipFree(b.d_prims);
+        (void)hipFree(b.d_wide);  // one allocation: d_prims points into it
         return nullptr;
     }
     auto *s = new nnbvh_scene;
@@ -238,6 +238,18 @@ static nnbvh_scene *scene_from_baked(const BakedScene &b, int depth, int device)
     s->d_prims = (float4 *)b.d_prims;
     s->device_bytes = (size_t)std::max(b.n_interior, 1) * sizeof(WideNode) +
                       std::max<size_t>((size_t)b.n_slots, 1) * 16;
+    if (const char *e = std::getenv("NNBVH_LAYOUT")) {  // memory order of records / leaves (bvh_layout.cpp)
+        const char *t = std::getenv("NNBVH_LAYOUT_TOP");
+        std::string err;
+        if (!relayout_scene(atoi(e), &s->d_wide, &s->d_prims, &s->n_interior, &s->n_slots, &s->root_ref,
+                            t ? atoi(t) : 12, &err)) {
+            set_error(err);
+            (void)hipFree(s->d_wide);
+            delete s;
+            return nullptr;
+        }
+        s->device_bytes = (size_t)std::max(s->n_interior, 1) * sizeof(WideNode) + (size_t)s->n_slots * 16;
+    }
     if (hipMalloc((void **)&s->d_stats, 16 * sizeof(unsigned long long)) == hipSuccess)
         (void)hipMemset(s->d_stats, 0, 16 * sizeof(unsigned long long));
     if (const char *e = std::getenv("NNBVH_STACK_WINDOW")) nnbvh_scene_set_option(s, "stack_window", atoi(e));
@@ -245,6 +257,7 @@ static nnbvh_scene *scene_from_baked(const BakedScene &b, int depth, int device)
     if (const char *e = std::getenv("NNBVH_XCD_QUEUES")) nnbvh_scene_set_option(s, "xcd_queues", atoi(e));
     if (const char *e = std::getenv("NNBVH_REFILL_WEIGHT")) nnbvh_scene_set_option(s, "refill_weight", atoi(e));
     if (const char *e = std::getenv("NNBVH_PRIM_WEIGHT")) nnbvh_scene_set_option(s, "prim_weight", atoi(e));
+    if (const char *e = std::getenv("NNBVH_PRIM_MIN")) nnbvh_scene_set_option(s, "prim_min", atoi(e));
     return s;
 }
 
@@ -460,18 +473,18 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     s->has_alpha = has_alpha ? 1 : 0;
     s->has_patches = 1;  // two-level scenes always run the general kernels
     s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
-    const size_t wide_bytes = wide.size() * sizeof(WideNode);
-    const size_t prim_bytes = std::max<size_t>((size_t)n_slots, 1) * 16;
-    bool ok = hip_ok(hipMalloc((void **)&s->d_wide, wide_bytes), "hipMalloc(nodes)") &&
-              hip_ok(hipMalloc((void **)&s->d_prims, prim_bytes), "hipMalloc(prims)") &&
-              hip_ok(hipMemcpy(s->d_wide, wide.data(), wide_bytes, hipMemcpyHostToDevice),
-                     "hipMemcpy(nodes)") &&
-              hip_ok(hipMemcpy(s->d_prims, stream.data(), (size_t)n_slots * 16,
-                               hipMemcpyHostToDevice),
-                     "hipMemcpy(prims)");
+    // one allocation, as bake_on_device makes it: records, then the 256-B aligned primitive stream + 64 B
+    const size_t wide_bytes = (wide.size() * sizeof(WideNode) + 255) & ~(size_t)255;
+    const size_t prim_bytes = std::max<size_t>((size_t)n_slots, 1) * 16 + 64;
+    bool ok = hip_ok(hipMalloc((void **)&s->d_wide, wide_bytes + prim_bytes), "hipMalloc(nodes + prims)");
+    if (ok) s->d_prims = (float4 *)((char *)s->d_wide + wide_bytes);
+    ok = ok && hip_ok(hipMemset((char *)s->d_prims + prim_bytes - 64, 0, 64), "hipMemset(pad)") &&
+         hip_ok(hipMemcpy(s->d_wide, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice),
+                "hipMemcpy(nodes)") &&
+         hip_ok(hipMemcpy(s->d_prims, stream.data(), (size_t)n_slots * 16, hipMemcpyHostToDevice),
+                "hipMemcpy(prims)");
     if (!ok) {
         if (s->d_wide) (void)hipFree(s->d_wide);
-        if (s->d_prims) (void)hipFree(s->d_prims);
         delete s;
         return nullptr;
     }
@@ -505,6 +518,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     if (const char *e = std::getenv("NNBVH_XCD_QUEUES")) nnbvh_scene_set_option(s, "xcd_queues", atoi(e));
     if (const char *e = std::getenv("NNBVH_REFILL_WEIGHT")) nnbvh_scene_set_option(s, "refill_weight", atoi(e));
     if (const char *e = std::getenv("NNBVH_PRIM_WEIGHT")) nnbvh_scene_set_option(s, "prim_weight", atoi(e));
+    if (const char *e = std::getenv("NNBVH_PRIM_MIN")) nnbvh_scene_set_option(s, "prim_min", atoi(e));
     return s;
 }
 
@@ -623,8 +637,7 @@ void nnbvh_scene_destroy(nnbvh_scene *s) {
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     for (void *p : s->scratch)
         if (p) (void)hipFree(p);
-    (void)hipFree(s->d_wide);
-    (void)hipFree(s->d_prims);
+    (void)hipFree(s->d_wide);  // d_prims points into the same allocation
     if (s->d_anim) (void)hipFree(s->d_anim);
     if (s->d_stats) (void)hipFree(s->d_stats);
     delete s;
@@ -646,6 +659,11 @@ int nnbvh_scene_bounds(const nnbvh_scene *s, float out[6]) {
 // kernel instances reach them with 32-bit byte offsets
 static int scene_fits32(const nnbvh_scene *s) {
     return (int64_t)s->n_interior < (1LL << 26) && s->n_slots < (1LL << 28) - 8;
+}
+// ... and the whole allocation (records, then the stream): a merged trip's one 32-bit offset reaches both
+static int scene_prim_min(const nnbvh_scene *s) {
+    const int64_t end = ((const char *)s->d_prims - (const char *)s->d_wide) + s->n_slots * 16 + 64;
+    return end < (1LL << 32) ? s->prim_min : 0;
 }
 
 static int grid_blocks(nnbvh_scene *s, int mode) {
@@ -721,6 +739,12 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
             return NNBVH_ERR_ARG;
         }
         s->int_repeat = value;
+    } else if (k == "prim_min") {
+        if (value < 0 || value > 64) {
+            set_error("set_option: prim_min must be 0..64");
+            return NNBVH_ERR_ARG;
+        }
+        s->prim_min = value;
     } else if (k == "prim_repeat") {
         if (value < 1 || value > 16) {
             set_error("set_option: prim_repeat must be 1..16");
@@ -793,6 +817,8 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     p.intRepeat = s->int_repeat;
     p.primRepeat = s->prim_repeat;
     p.fits32 = scene_fits32(s);
+    p.primsOff = (unsigned)((const char *)s->d_prims - (const char *)s->d_wide);
+    p.primMin = scene_prim_min(s);
     p.hasHostPrims = s->has_host_prims;
     p.spill = w->spill;
     p.anim = s->d_anim;
@@ -904,6 +930,8 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
         p.intRepeat = s->int_repeat;
         p.primRepeat = s->prim_repeat;
         p.fits32 = scene_fits32(s);
+        p.primsOff = (unsigned)((const char *)s->d_prims - (const char *)s->d_wide);
+        p.primMin = scene_prim_min(s);
         p.hasHostPrims = s->has_host_prims;
         p.spill = w->spill;
         p.anim = s->d_anim;

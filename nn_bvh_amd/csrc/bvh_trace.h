@@ -34,6 +34,8 @@ struct TraceParams {
     int intRepeat;          // interior steps per scheduling decision (>= 1)
     int primRepeat;         // primitive steps per scheduling decision (>= 1)
     int fits32;             // wide[] and prims[] are both below 4 GiB: the lean instances' 32-bit offsets reach them
+    unsigned primsOff;      // byte offset of prims[] from wide[] (one allocation; lean instances, merged trips)
+    int primMin;            // merged trips: lanes that must wait on a leaf before the primitive block runs; 0 = separate trips
     unsigned long long *stats;  // NNBVH_STATS builds: trips/lanes per step kind; else unused
     uint2 *spill;           // [kMaxStack][grid threads] overflow of the LDS stack window
     const float *anim;      // two-level scenes: kAnimStride floats per instance (anim_math.h), or null
@@ -46,6 +48,10 @@ struct TraceParams {
     void *bOut[kMaxFusedBatches];
     long bN[kMaxFusedBatches];
 };
+
+// bvh_layout.cpp: re-orders the baked arrays in memory (speed only; see the modes there)
+bool relayout_scene(int mode, float4 **d_wide, float4 **d_prims, int *n_interior, int64_t *n_slots, int *root_ref,
+                    int top_levels, std::string *error);
 
 hipError_t launch_zero_queue(unsigned *queue, int words, hipStream_t stream);
 

@@ -64,8 +64,17 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 #ifndef NNBVH_FUSED_PRIM_LOOP
 #define NNBVH_FUSED_PRIM_LOOP 0
 #endif
+#ifndef NNBVH_LEAN_PRIM_LOOP
+#define NNBVH_LEAN_PRIM_LOOP 1
+#endif
 #ifndef NNBVH_LEAN_EXTRA_WAVES
 #define NNBVH_LEAN_EXTRA_WAVES 2
+#endif
+// 1: the lean instances run MERGED trips (see the scheduling loop): every lane with a node OR a primitive
+// pending fetches in the same trip, through one load sequence, and the two kinds of arithmetic follow
+// each other — a lane waiting on a leaf no longer sits out the interior trips of its wavefront.
+#ifndef NNBVH_MERGED
+#define NNBVH_MERGED 0
 #endif
 //
 // INST = 1: the scene is two-level (TransformedPrimitive leaves, cpu/primitive.cpp:112-131).  An
@@ -246,6 +255,146 @@ void trace_kernel(TraceParams p) {
         cur = (resume == kDone) ? pop_next() : resume;
     };
 
+    // one primitive of the lane's leaf, its three slots s0..s2 in hand: the Primitive tag dispatch
+    // (cpu/primitive.h), the leaf test, what a hit does, and where the lane goes next
+    auto prim_math = [&](const int slot, const float4 s0, const float4 s1, const float4 s2) {
+        const unsigned flags = __float_as_uint(s1.w);
+        if (INST && (flags & kPrimInstance)) {
+            enter_instance(slot, flags, s0, s1, s2);
+        } else if (!kLean && (flags & kPrimHost)) {
+            // a primitive only the host can intersect (quadric, curve, alpha-tested
+            // ...): this ray's result is void and the caller re-traces it on the CPU
+            cold[kColdHost][lane] = 1.0f;
+            cur = (flags & kPrimLast) ? pop_next() : ~(slot + 3);
+        } else {
+            tests += 1;
+            bool hit;
+            float x0, x1, x2, th;
+            int next;
+            if (!PATCH || !(flags & kPrimPatch)) {
+                hit = triangle_test(r, tMax, (flags & kPrimDegenerate) != 0,
+                                    {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                    {s2.x, s2.y, s2.z}, x0, x1, x2, th);
+                next = slot + 3;
+                if (ALPHA && hit && (flags & kPrimAlpha)) {
+                    // GeometricPrimitive::Intersect, cpu/primitive.cpp:57-70 (IntersectP takes
+                    // the same route, :79-81): stochastic alpha test on the ray as given
+                    const float a = s2.w;
+                    if (a < 1) {
+                        const V3 rd = {cold[kColdD][lane], cold[kColdD + 1][lane],
+                                       cold[kColdD + 2][lane]};
+                        const float u = (a <= 0) ? 1.f : hash_float_6f(r.o, rd);
+                        if (u > a) {
+                            // ignored; the reference re-traces from the hit point against this
+                            // shape alone: rNext = si->intr.SpawnRay(r.d), Intersect(rNext, tMax - tHit)
+                            hit = false;
+                            RayState rn = r;  // same direction: same reciprocals and shear
+                            rn.o = alpha_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                                        {s2.x, s2.y, s2.z}, x0, x1, x2,
+                                                        (flags & kPrimFlipN) != 0, rd);
+                            tests += 1;  // Triangle::Intersect counts the re-test too
+                            float y0, y1, y2, tn;
+                            if (triangle_test(rn, tMax - th, (flags & kPrimDegenerate) != 0,
+                                              {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                              {s2.x, s2.y, s2.z}, y0, y1, y2, tn))
+                                cold[kColdHost][lane] = 1.0f;  // never for a planar triangle; if
+                                                               // it happens the ray is the caller's
+                        }
+                    }
+                }
+            } else {
+                const float4 s3 = p.prims[slot + 3];
+                x2 = 0.0f;
+                const V3 rd = {cold[PATCH ? kColdD : 0][lane], cold[PATCH ? kColdD + 1 : 0][lane],
+                               cold[PATCH ? kColdD + 2 : 0][lane]};
+                hit = patch_test(r, rd, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                 {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
+                next = slot + 4;
+            }
+            bool closestLane = MODE == 0;
+            if (MODE == 3 && hit)
+                closestLane = !((p.anyMask >> ((kLean ? riReg : __float_as_int(cold[kColdRi][lane])) >> kFusedIndexBits)) & 1u);
+            if (hit) {
+                if (closestLane) {
+                    cold[kColdHit][lane] = s0.w;  // primitive id bits
+                    cold[kColdHit + 1][lane] = x0;
+                    cold[kColdHit + 2][lane] = x1;
+                    cold[kColdHit + 3][lane] = x2;
+                    tMax = th;
+                    if (INST) {
+                        cold[kHitInst][lane] = cold[kCurInst][lane];
+                        cold[kInnerHit][lane] = 1.0f;
+                    }
+                } else {
+                    found = true;
+                }
+            }
+            if (MODE != 0 && found) cur = kDone;           // aggregates.cpp:597-602
+            else if (flags & kPrimLast) cur = pop_next();  // leaf finished
+            else cur = ~next;
+        }
+    };
+
+    // one interior record q0..q3 in hand: both children's slab keys, the far child pushed with its key,
+    // the near child entered (aggregates.cpp:556-574)
+    auto interior_math = [&](const float4 q0, const float4 q1, const float4 q2, const float4 q3) {
+        const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
+        const int axis = __float_as_int(q3.z);
+        // aggregates.cpp:562-568: near child = second child iff dirIsNeg[axis]
+        const bool swap = ((r.kz >> axis) & 1) != 0;  // dirIsNeg[axis], packed by ray_shear
+        // one float per child: its entry distance, +inf if the box is missed whatever tMax is
+        // (slab_entry_key) — the verdicts are then two compares against tMax
+        const float k0 = slab_entry_key(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r);
+        const float k1 = slab_entry_key(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r);
+        const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
+        const float nearT = swap ? k1 : k0, farT = swap ? k0 : k1;
+        visited += 1;  // the near child is entered now
+        // A far child whose tMax-independent tests failed (key +inf) can never be entered: it is
+        // counted now and not pushed.  One that merely fails against TODAY's tMax must be pushed:
+        // tMax is not monotone — a hit accepted with tScaled <= tMax * det can round to a t one ulp
+        // ABOVE the old tMax (shapes.cpp:239-244; rays that meet a shared vertex at exactly tMax do
+        // it), and the reference tests the far child against that later value.  MODE 1 pushes every
+        // far child (exact counts up to the first hit).
+        const bool doPush = (MODE == 1) || (farT < __builtin_inff());
+        if (doPush && sp - base == W - 1) {
+            uint2 e;
+            e.x = __float_as_uint(stk[base & (W - 1)][0][lane]);
+            e.y = __float_as_uint(stk[base & (W - 1)][1][lane]);
+            p.spill[(long)base * spillStride + gtid] = e;
+            ++base;
+        }
+        stk[sp & (W - 1)][0][lane] = __int_as_float(farRef);
+        stk[sp & (W - 1)][1][lane] = farT;
+        sp += doPush ? 1 : 0;
+        if (MODE == 0 || MODE == 3) visited += doPush ? 0 : 1;
+        if (nearT < tMax) cur = nearRef;
+        else cur = pop_next();
+    };
+    auto interior_step = [&]() {
+#ifdef NNBVH_STATS
+        st[14] += 1;
+        st[15] += __popcll(__ballot(cur >= 0));
+#endif
+        if (cur >= 0) {
+#ifdef NNBVH_PROBE_SALU  // sensitivity probes (tools only): extra scalar / vector instructions per interior step
+#pragma unroll
+            for (int k = 0; k < NNBVH_PROBE_SALU; ++k) asm volatile("s_add_u32 s95, s95, 1" ::: "s95", "scc");
+#endif
+#ifdef NNBVH_PROBE_VALU
+#pragma unroll
+            for (int k = 0; k < NNBVH_PROBE_VALU; ++k) asm volatile("v_add_u32 %0, %0, 1" : "+v"(tests));
+#endif
+            // lean instances address records and slots with a 32-bit byte offset from a scalar base (one
+            // 32-bit shift instead of a 64-bit shift and a 64-bit add per fetch); the launcher only picks
+            // them when both arrays are below 4 GiB (p.fits32)
+            const float4 *rec = kLean ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.wide) + ((unsigned)cur << 6))
+                                      : p.wide + 4 * (long)cur;
+            const float4 q3 = rec[3];
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            interior_math(q0, q1, q2, q3);
+        }
+    };
+
     for (;;) {
 #ifdef NNBVH_STATS
         {
@@ -410,13 +559,42 @@ void trace_kernel(TraceParams p) {
             continue;
         }
 
+        if (kLean && NNBVH_MERGED && p.primMin > 0) {
+            // ---- merged trip (lean instances): every lane with a node pending, and — when at least
+            // p.primMin lanes wait on a leaf, or nobody has a node — every lane with a primitive pending,
+            // fetches 64 B through ONE load sequence (records and slots live in one allocation: a lane's
+            // 32-bit offset reaches either), then the two kinds of arithmetic follow each other.  A trip
+            // costs one round trip to memory whichever lanes take part; lanes waiting on a leaf no longer
+            // sit out their wavefront's interior trips.  (A primitive lane's fourth slot is not used.)
+            const bool primLane = !isInt && !isIdle && (nPrim >= p.primMin || nInt == 0);
+#ifdef NNBVH_STATS
+            st[0] += 1;
+            st[1] += nInt;
+            if (nPrim >= p.primMin || nInt == 0) {
+                st[2] += 1;
+                st[3] += nPrim;
+            }
+            stKind = 0;
+#endif
+            if (isInt || primLane) {
+                const unsigned off = isInt ? ((unsigned)cur << 6) : (p.primsOff + ((unsigned)~cur << 4));
+                const float4 *rec = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.wide) + off);
+                const float4 q3 = rec[3];
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                if (isInt) interior_math(q0, q1, q2, q3);
+                else prim_math(~cur, q0, q1, q2);
+            }
+            for (int rep = 1; rep < p.intRepeat && __ballot(cur >= 0) != 0ull; ++rep) interior_step();
+            continue;
+        }
+
         if (sP > sI || nInt == 0) {
             // ---- primitive step: lanes with a pending leaf test ONE primitive -----------
             // (up to p.primRepeat of them per scheduling decision: lanes whose leaf is finished sit the
             // rest out, lanes still inside theirs go on without another round of ballots)
             // (the one-launch kernel and the lean instances keep ONE: compiled in, the loop costs them 6
             // registers — spills at 8 wavefronts per SIMD — and 2.6 % / 8 % of their rate)
-            const int nPrep = ((MODE == 3 && !NNBVH_FUSED_PRIM_LOOP) || kLean) ? 1 : p.primRepeat;
+            const int nPrep = ((MODE == 3 && !NNBVH_FUSED_PRIM_LOOP) || (kLean && !NNBVH_LEAN_PRIM_LOOP)) ? 1 : p.primRepeat;
             int prep = 0;
             do {
             if (cur < 0 && cur != kDone) {
@@ -431,141 +609,13 @@ void trace_kernel(TraceParams p) {
                     // dependent trips to memory per primitive
                     asm volatile("" : "+v"(s0.x), "+v"(s0.y), "+v"(s0.z), "+v"(s0.w), "+v"(s1.x), "+v"(s1.y),
                                       "+v"(s1.z), "+v"(s1.w), "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(s2.w));
-                    const unsigned flags = __float_as_uint(s1.w);
-                    if (INST && (flags & kPrimInstance)) {
-                        enter_instance(slot, flags, s0, s1, s2);
-                    } else if (!kLean && (flags & kPrimHost)) {
-                        // a primitive only the host can intersect (quadric, curve, alpha-tested
-                        // ...): this ray's result is void and the caller re-traces it on the CPU
-                        cold[kColdHost][lane] = 1.0f;
-                        cur = (flags & kPrimLast) ? pop_next() : ~(slot + 3);
-                    } else {
-                        tests += 1;
-                        bool hit;
-                        float x0, x1, x2, th;
-                        int next;
-                        if (!PATCH || !(flags & kPrimPatch)) {
-                            hit = triangle_test(r, tMax, (flags & kPrimDegenerate) != 0,
-                                                {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                                {s2.x, s2.y, s2.z}, x0, x1, x2, th);
-                            next = slot + 3;
-                            if (ALPHA && hit && (flags & kPrimAlpha)) {
-                                // GeometricPrimitive::Intersect, cpu/primitive.cpp:57-70 (IntersectP takes
-                                // the same route, :79-81): stochastic alpha test on the ray as given
-                                const float a = s2.w;
-                                if (a < 1) {
-                                    const V3 rd = {cold[kColdD][lane], cold[kColdD + 1][lane],
-                                                   cold[kColdD + 2][lane]};
-                                    const float u = (a <= 0) ? 1.f : hash_float_6f(r.o, rd);
-                                    if (u > a) {
-                                        // ignored; the reference re-traces from the hit point against this
-                                        // shape alone: rNext = si->intr.SpawnRay(r.d), Intersect(rNext, tMax - tHit)
-                                        hit = false;
-                                        RayState rn = r;  // same direction: same reciprocals and shear
-                                        rn.o = alpha_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                                                    {s2.x, s2.y, s2.z}, x0, x1, x2,
-                                                                    (flags & kPrimFlipN) != 0, rd);
-                                        tests += 1;  // Triangle::Intersect counts the re-test too
-                                        float y0, y1, y2, tn;
-                                        if (triangle_test(rn, tMax - th, (flags & kPrimDegenerate) != 0,
-                                                          {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                                          {s2.x, s2.y, s2.z}, y0, y1, y2, tn))
-                                            cold[kColdHost][lane] = 1.0f;  // never for a planar triangle; if
-                                                                           // it happens the ray is the caller's
-                                    }
-                                }
-                            }
-                        } else {
-                            const float4 s3 = p.prims[slot + 3];
-                            x2 = 0.0f;
-                            const V3 rd = {cold[PATCH ? kColdD : 0][lane], cold[PATCH ? kColdD + 1 : 0][lane],
-                                           cold[PATCH ? kColdD + 2 : 0][lane]};
-                            hit = patch_test(r, rd, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                             {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
-                            next = slot + 4;
-                        }
-                        bool closestLane = MODE == 0;
-                        if (MODE == 3 && hit)
-                            closestLane = !((p.anyMask >> ((kLean ? riReg : __float_as_int(cold[kColdRi][lane])) >> kFusedIndexBits)) & 1u);
-                        if (hit) {
-                            if (closestLane) {
-                                cold[kColdHit][lane] = s0.w;  // primitive id bits
-                                cold[kColdHit + 1][lane] = x0;
-                                cold[kColdHit + 2][lane] = x1;
-                                cold[kColdHit + 3][lane] = x2;
-                                tMax = th;
-                                if (INST) {
-                                    cold[kHitInst][lane] = cold[kCurInst][lane];
-                                    cold[kInnerHit][lane] = 1.0f;
-                                }
-                            } else {
-                                found = true;
-                            }
-                        }
-                        if (MODE != 0 && found) cur = kDone;           // aggregates.cpp:597-602
-                        else if (flags & kPrimLast) cur = pop_next();  // leaf finished
-                        else cur = ~next;
-                    }
+                    prim_math(slot, s0, s1, s2);
                 }
             }
             } while (++prep < nPrep && __ballot(cur < 0 && cur != kDone) != 0ull);
         } else {
             // ---- interior step(s): up to p.intRepeat in a row before the next scheduling
             // decision (lanes that leave the interior state sit the remaining ones out) -------
-            auto interior_step = [&]() {
-#ifdef NNBVH_STATS
-                st[14] += 1;
-                st[15] += __popcll(__ballot(cur >= 0));
-#endif
-                if (cur >= 0) {
-#ifdef NNBVH_PROBE_SALU  // sensitivity probes (tools only): extra scalar / vector instructions per interior step
-#pragma unroll
-                for (int k = 0; k < NNBVH_PROBE_SALU; ++k) asm volatile("s_add_u32 s95, s95, 1" ::: "s95", "scc");
-#endif
-#ifdef NNBVH_PROBE_VALU
-#pragma unroll
-                for (int k = 0; k < NNBVH_PROBE_VALU; ++k) asm volatile("v_add_u32 %0, %0, 1" : "+v"(tests));
-#endif
-                // lean instances address records and slots with a 32-bit byte offset from a scalar base (one
-                // 32-bit shift instead of a 64-bit shift and a 64-bit add per fetch); the launcher only picks
-                // them when both arrays are below 4 GiB (p.fits32)
-                const float4 *rec = kLean ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.wide) + ((unsigned)cur << 6))
-                                          : p.wide + 4 * (long)cur;
-                const float4 q3 = rec[3];
-                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-                const int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y);
-                const int axis = __float_as_int(q3.z);
-                // aggregates.cpp:562-568: near child = second child iff dirIsNeg[axis]
-                const bool swap = ((r.kz >> axis) & 1) != 0;  // dirIsNeg[axis], packed by ray_shear
-                // one float per child: its entry distance, +inf if the box is missed whatever tMax is
-                // (slab_entry_key) — the verdicts are then two compares against tMax
-                const float k0 = slab_entry_key(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r);
-                const float k1 = slab_entry_key(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r);
-                const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
-                const float nearT = swap ? k1 : k0, farT = swap ? k0 : k1;
-                visited += 1;  // the near child is entered now
-                // A far child whose tMax-independent tests failed (key +inf) can never be entered: it is
-                // counted now and not pushed.  One that merely fails against TODAY's tMax must be pushed:
-                // tMax is not monotone — a hit accepted with tScaled <= tMax * det can round to a t one ulp
-                // ABOVE the old tMax (shapes.cpp:239-244; rays that meet a shared vertex at exactly tMax do
-                // it), and the reference tests the far child against that later value.  MODE 1 pushes every
-                // far child (exact counts up to the first hit).
-                const bool doPush = (MODE == 1) || (farT < __builtin_inff());
-                if (doPush && sp - base == W - 1) {
-                    uint2 e;
-                    e.x = __float_as_uint(stk[base & (W - 1)][0][lane]);
-                    e.y = __float_as_uint(stk[base & (W - 1)][1][lane]);
-                    p.spill[(long)base * spillStride + gtid] = e;
-                    ++base;
-                }
-                stk[sp & (W - 1)][0][lane] = __int_as_float(farRef);
-                stk[sp & (W - 1)][1][lane] = farT;
-                sp += doPush ? 1 : 0;
-                if (MODE == 0 || MODE == 3) visited += doPush ? 0 : 1;
-                if (nearT < tMax) cur = nearRef;
-                else cur = pop_next();
-                }
-            };
             if (MODE == 3) {
                 // the one-launch kernel: the first three steps (the default int_repeat) written out, no trip
                 // counter to maintain (+0.8 %; the separate-launch kernels lose 1.8 % with it and keep the loop)

@@ -75,19 +75,21 @@ __global__ __launch_bounds__(kFilmBlock) void film_add_samples(
 
 __global__ __launch_bounds__(kFilmBlock) void film_pack(const double2 *__restrict__ pixels,
                                                         const int32_t *__restrict__ index, long n,
-                                                        double2 *__restrict__ out) {
+                                                        double2 *__restrict__ out, long nPixels) {
     for (long i = (long)blockIdx.x * kFilmBlock + threadIdx.x; i < n; i += (long)gridDim.x * kFilmBlock) {
         const long p = index[i];
-        out[2 * i] = pixels[2 * p];
-        out[2 * i + 1] = pixels[2 * p + 1];
+        const bool inside = p >= 0 && p < nPixels;  // an index outside the film packs zeros, never faults
+        out[2 * i] = inside ? pixels[2 * p] : make_double2(0, 0);
+        out[2 * i + 1] = inside ? pixels[2 * p + 1] : make_double2(0, 0);
     }
 }
 
 __global__ __launch_bounds__(kFilmBlock) void film_unpack(double2 *__restrict__ pixels,
                                                           const int32_t *__restrict__ index, long n,
-                                                          const double2 *__restrict__ in) {
+                                                          const double2 *__restrict__ in, long nPixels) {
     for (long i = (long)blockIdx.x * kFilmBlock + threadIdx.x; i < n; i += (long)gridDim.x * kFilmBlock) {
         const long p = index[i];
+        if (p < 0 || p >= nPixels) continue;  // outside the film: skipped
         pixels[2 * p] = in[2 * i];
         pixels[2 * p + 1] = in[2 * i + 1];
     }
@@ -231,10 +233,12 @@ static int film_move(nnbvh_film *f, const int32_t *d_index, int64_t n, void *d_b
     if (!guard.ok) return NNBVH_ERR_DEVICE;
     if (pack)
         hipLaunchKernelGGL(film_pack, dim3(film_grid(n)), dim3(kFilmBlock), 0, (hipStream_t)stream,
-                           (const double2 *)f->d_pixels, d_index, (long)n, (double2 *)d_buf);
+                           (const double2 *)f->d_pixels, d_index, (long)n, (double2 *)d_buf,
+                           (long)(f->x1 - f->x0) * (f->y1 - f->y0));
     else
         hipLaunchKernelGGL(film_unpack, dim3(film_grid(n)), dim3(kFilmBlock), 0, (hipStream_t)stream,
-                           (double2 *)f->d_pixels, d_index, (long)n, (const double2 *)d_buf);
+                           (double2 *)f->d_pixels, d_index, (long)n, (const double2 *)d_buf,
+                           (long)(f->x1 - f->x0) * (f->y1 - f->y0));
     return film_hip_ok(hipGetLastError(), "film pack/unpack launch") ? NNBVH_OK : NNBVH_ERR_DEVICE;
 }
 

@@ -69,25 +69,44 @@ class Film:
         check(_lib.lib().nnbvh_film_unpack_pixels_device(self._h, _dp(d_index), n, _dp(d_in),
                                                          ctypes.c_void_p(stream)), "nnbvh_film_unpack_pixels_device")
 
-    def all_gather_tiles(self, index_lists, rank, stream=0, group=None):
-        """The film all-gather of a tile-sharded render: index_lists[r] = int32 CUDA tensor of the
-        linear pixel indices rank r owns.  Packs this rank's pixels, ONE all_gather_into_tensor
-        (RCCL over xGMI under the nccl backend; ranks pad to the largest shard), unpacks the other
-        ranks' pixels into this film.  Returns the bytes this rank sent."""
+    def gather_tiles(self, index_lists, rank, stream=None, group=None):
+        """Packs this rank's pixels and all-gathers every rank's (ONE all_gather_into_tensor: RCCL over
+        xGMI under the nccl backend; ranks pad to the largest shard).  Returns the float64 tensor
+        [world, width, 4].  Everything is ordered on ONE stream: torch's current stream, or `stream` (a raw
+        hipStream_t) made current for the duration — the collective orders itself against torch's current
+        stream only, and the temporaries are then allocated on the stream that uses them."""
+        import contextlib
+
         import torch
         import torch.distributed as dist
         world = len(index_lists)
         width = max(int(ix.numel()) for ix in index_lists)
         dev = index_lists[rank].device
-        send = torch.zeros((width, 4), dtype=torch.float64, device=dev)
-        self.pack(index_lists[rank], int(index_lists[rank].numel()), send, stream)
-        out = torch.empty((world * width, 4), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(out, send, group=group)
-        out = out.view(world, width, 4)
-        for r in range(world):
-            if r != rank:
-                self.unpack(index_lists[r], int(index_lists[r].numel()), out[r], stream)
-        return width * 32
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)) if stream else contextlib.nullcontext()
+        with ctx:
+            cur = torch.cuda.current_stream(dev).cuda_stream
+            send = torch.zeros((width, 4), dtype=torch.float64, device=dev)
+            self.pack(index_lists[rank], int(index_lists[rank].numel()), send, cur)
+            out = torch.empty((world * width, 4), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(out, send, group=group)
+        return out.view(world, width, 4)
+
+    def all_gather_tiles(self, index_lists, rank, stream=None, group=None):
+        """The film all-gather of a tile-sharded render: index_lists[r] = int32 CUDA tensor of the
+        linear pixel indices rank r owns.  gather_tiles, then the other ranks' pixels are unpacked into
+        this film — on the same stream.  Returns the bytes this rank sent."""
+        import contextlib
+
+        import torch
+        dev = index_lists[rank].device
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)) if stream else contextlib.nullcontext()
+        with ctx:
+            out = self.gather_tiles(index_lists, rank, None, group)
+            cur = torch.cuda.current_stream(dev).cuda_stream
+            for r in range(len(index_lists)):
+                if r != rank:
+                    self.unpack(index_lists[r], int(index_lists[r].numel()), out[r], cur)
+        return int(out.shape[1]) * 32
 
 
 def pixel_rgb(pixels):

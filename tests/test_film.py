@@ -101,6 +101,41 @@ def test_device_film_equals_oracle(stride, clamp, passes):
     other.close()
 
 
+@pytest.mark.gpu
+def test_film_all_gather_under_rccl_on_a_side_stream():
+    """Film.gather_tiles / all_gather_tiles with CUDA tensors under the nccl (= RCCL) backend, world 1 on the
+    one device, on a NON-default stream: pack -> all_gather_into_tensor -> consumer must be ordered on that
+    stream (the collective orders itself against torch's current stream only)."""
+    from nn_bvh_amd.film import Film
+    xres, yres, n_slots, passes = 320, 200, 40000, 3
+    px, py, rgb, w = _samples(11, xres, yres, n_slots, passes, 3)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        side = torch.cuda.Stream()
+        film, other = Film(xres, yres), Film(xres, yres)
+        d = [torch.from_numpy(a).cuda() for a in (px, py, rgb, w)]
+        ok = (px >= 0) & (px < xres) & (py >= 0) & (py < yres)  # _samples puts some outside the film on purpose
+        idx = torch.from_numpy(np.unique(py[ok].astype(np.int64) * xres + px[ok]).astype(np.int32)).cuda()
+        torch.cuda.synchronize()
+        raw = side.cuda_stream
+        # the producer of the film's content runs on the side stream too, right before the gather
+        film.add_samples_device(d[0], d[1], d[2], d[3], n_slots, passes, rgb_stride=3, stream=raw)
+        out = film.gather_tiles([idx], 0, stream=raw)
+        other.unpack(idx, int(idx.numel()), out[0], raw)
+        sent = film.all_gather_tiles([idx], 0, stream=raw)  # world 1: nothing to unpack, must not disturb the film
+        side.synchronize()
+        assert sent == int(idx.numel()) * 32
+        exp = ob.film_add_samples(np.zeros((xres * yres, 4)), (0, 0, xres, yres), float("inf"), px, py, rgb, w, passes)
+        assert film.read().tobytes() == exp.tobytes()
+        assert other.read().tobytes() == exp.tobytes()  # every touched pixel arrived, the rest is zero in both
+        assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+        film.close()
+        other.close()
+    finally:
+        dist.destroy_process_group()
+
+
 # ---- N > 1 on CPU: tiles of the film are accumulated by their ranks and all-gathered ------------
 CAM = ((0, 12, 0.5), (0, 0, 0), (0, 1, 0), 50.0, 96, 80)
 SPP = 3

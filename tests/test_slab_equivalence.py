@@ -21,9 +21,9 @@ def entry_key(box, o, d):
         neg = inv < 0
         lo, hi = box[:, 0:3], box[:, 3:6]
         a = (np.where(neg, hi, lo) - o) * inv
-        b = ((np.where(neg, lo, hi) - o) * inv) * WIDEN
+        b = (np.where(neg, lo, hi) - o) * inv
         amax = np.fmax(np.fmax(a[:, 0], a[:, 1]), a[:, 2])
-        bmin = np.fmin(np.fmin(b[:, 0], b[:, 1]), b[:, 2])
+        bmin = np.fmin(np.fmin(b[:, 0], b[:, 1]), b[:, 2]) * WIDEN  # widened once: the product is monotone
         ok = ~(np.isnan(a[:, 0]) | np.isnan(b[:, 0])) & (amax <= bmin) & (bmin > 0)
         return np.where(ok, amax, F(np.inf)).astype(F)
 
