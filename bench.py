@@ -635,8 +635,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.scene}, {xres}x{yres}: one wavefront pass of {total_spp} spp per step "
-                            f"({args.spp} spp per GPU-film) — primary + diffuse-bounce closest-hit, shadow "
-                            f"any-hit towards the light quads, RecordShadowRayResult + RGBFilm::AddSample into a "
+                            f"({args.spp} spp per GPU-film) — primary, bounce-1 and bounce-2 closest-hit, shadow "
+                            f"any-hit towards the light quads (batches pre-generated, hence independent: ONE launch; the "
+                            f"dependent form is dependent_step), rays in --ray-order {args.ray_order} (a caller-side "
+                            f"order the reference's integrator does not form: ray_order_probe), "
+                            f"RecordShadowRayResult + RGBFilm::AddSample into a "
                             f"4-doubles-per-pixel film; {args.steps} steps rotating over {len(sets)} distinct "
                             f"sample sets; BASELINE's 1024 spp = {1024 // max(1, total_spp)} such passes, "
                             f"extrapolated per SURVEY §8d (>= 64 M rays per class timed), not traced",
@@ -653,14 +656,16 @@ def main():
                 "nodes": int(len(tree.nodes)),
                 "rays_primary": int(n_primary),
                 "rays_bounce": int(n_bounce),
+                "rays_bounce2": int(n_bounce2),
                 "rays_shadow": int(n_shadow),
                 "rays_per_step_per_gpu": int(rays_per_step),
                 "parallelism": f"tile-sharded x{world}, BVH replicated, film all-gather after the pass",
-                "launches_per_step": "1 (nnbvh_trace_batches_device, mode-3 kernel)" if fused else "3",
+                "launches_per_step": "1 (nnbvh_trace_batches_device, mode-3 kernel)" if fused else "4",
             },
             "per_class_mrays": {
                 "primary_closest": round(n_primary / ms_primary / 1e3, 2),
                 "bounce_closest": round(n_bounce / ms_bounce / 1e3, 2),
+                "bounce2_closest": round(n_bounce2 / ms_bounce2 / 1e3, 2),
                 "shadow_any": round(n_shadow / ms_shadow / 1e3, 2),
             },
             "film": {
@@ -711,6 +716,10 @@ def main():
                 },
             },
         }
+        if order_probe is not None:
+            result["ray_order_probe"] = order_probe
+        if world > 1:
+            result["rccl_ranks_seen"] = int(dist.get_world_size()) if backend == "nccl" else 0
         if overlapped_s is not None:
             result["overlapped_batches"] = {
                 "value": round(rays_per_step * world * args.steps / overlapped_s / 1e6, 2),
@@ -719,12 +728,14 @@ def main():
                 "how": "the three traces of sample set 0 as concurrent launches on internal streams",
             }
         if wavefront_s is not None:
-            result["wavefront_queues"] = {
+            result["dependent_step"] = {
                 "value": round(rays_per_step * world * args.steps / wavefront_s / 1e6, 2),
                 "unit": "Mray/s",
                 "ms_per_step": round(wavefront_s / args.steps * 1e3, 4),
-                "how": "same step through nnbvh_wavefront_intersect_closest/_shadow: SOA queues in, "
-                       "6 index queues + pixel radiance out, queue resets included",
+                "how": "the same four batches through nnbvh_wavefront_intersect_closest/_shadow, one launch per "
+                       "queue (what an integrator whose bounce rays depend on the previous hits must issue): SOA "
+                       "queues in, 6 index queues + pixel radiance out, queue resets included; `value` is the one-"
+                       "launch form, which needs independent batches",
                 "with_surface_interactions_ms_per_step": round(wavefront_intr_s / args.steps * 1e3, 4),
             }
         if film_allgather_ms is not None:

@@ -52,7 +52,12 @@ struct HitRecord {
     int prim;
     float tHit;
     float b0, b1, b2;  // patch: b0 = u, b1 = v
+    int instance = 0;  // 0 = top level, k + 1 = inside instance k (nnbvh_hit.instance)
 };
+// A ray whose result is VOID: a primitive only the host can intersect (NNBVH_PRIM_HOST: quadric, curve,
+// textured alpha ...) lay on its way, so neither "hit", "miss" nor "occluded" is known and the caller must
+// re-trace it on the CPU (nnbvh_hit.instance == -1 / occluded == 2).  The single-ray adapters report it
+// through the optional `needsHost` out-parameter; without one such a ray is fatal, never a silent answer.
 
 class HipBVHAggregate {
   public:
@@ -70,15 +75,22 @@ class HipBVHAggregate {
 
     // == BVHAggregate::Create / ctor (aggregates.cpp:725-744, 140-190): builds on the host.
     // splitMethod: "sah" (default) | "middle" | "equal"; maxPrimsInNode default 4.
+    // primBounds: 6 floats (min, max) per primitive, read for NNBVH_PRIM_HOST / NNBVH_PRIM_INSTANCE entries
+    // (what Primitive::Bounds() returns for them); may be null when the list holds neither
     HipBVHAggregate(const std::vector<nnbvh_prim> &prims, const std::vector<float> &verts,
-                    int maxPrimsInNode = 4, const std::string &splitMethod = "sah", int device = 0) {
+                    int maxPrimsInNode = 4, const std::string &splitMethod = "sah", int device = 0,
+                    const std::vector<float> *primBounds = nullptr) {
         int method = splitMethod == "sah"      ? NNBVH_SPLIT_SAH
                      : splitMethod == "middle" ? NNBVH_SPLIT_MIDDLE
                      : splitMethod == "equal"  ? NNBVH_SPLIT_EQUAL_COUNTS
                      : splitMethod == "hlbvh"  ? NNBVH_SPLIT_HLBVH
                                                : -1;
-        nnbvh_build *b = nnbvh_build_create(prims.data(), (int)prims.size(), verts.data(),
-                                            (int)(verts.size() / 3), maxPrimsInNode, method);
+        nnbvh_build *b = primBounds
+                             ? nnbvh_build_create_with_bounds(prims.data(), (int)prims.size(), verts.data(),
+                                                              (int)(verts.size() / 3), primBounds->data(),
+                                                              maxPrimsInNode, method)
+                             : nnbvh_build_create(prims.data(), (int)prims.size(), verts.data(),
+                                                  (int)(verts.size() / 3), maxPrimsInNode, method);
         if (!b) {
             fatal("HipBVHAggregate: build");
             return;
@@ -110,21 +122,30 @@ class HipBVHAggregate {
         return {{b[0], b[1], b[2]}, {b[3], b[4], b[5]}};
     }
 
-    std::optional<HitRecord> Intersect(const Ray &ray,
-                                       float tMax = std::numeric_limits<float>::infinity()) const {
+    std::optional<HitRecord> Intersect(const Ray &ray, float tMax = std::numeric_limits<float>::infinity(),
+                                       bool *needsHost = nullptr) const {
         nnbvh_ray r = wire(ray, tMax);
         nnbvh_hit h;
         if (nnbvh_intersect_closest(scene_, &r, 1, &h) != NNBVH_OK) fatal("Intersect");
+        if (needsHost) *needsHost = h.instance == -1;
+        if (h.instance == -1) {
+            if (!needsHost) fatal("Intersect: the ray met a host-only primitive (pass needsHost and re-trace it on the CPU)");
+            return {};
+        }
         if (h.prim < 0) return {};
-        return HitRecord{h.prim, h.t, h.b0, h.b1, h.b2};
+        return HitRecord{h.prim, h.t, h.b0, h.b1, h.b2, h.instance};
     }
 
-    bool IntersectP(const Ray &ray, float tMax = std::numeric_limits<float>::infinity()) const {
+    bool IntersectP(const Ray &ray, float tMax = std::numeric_limits<float>::infinity(),
+                    bool *needsHost = nullptr) const {
         nnbvh_ray r = wire(ray, tMax);
         uint8_t occ = 0;
         if (nnbvh_intersect_any(scene_, &r, 1, &occ, nullptr, nullptr) != NNBVH_OK)
             fatal("IntersectP");
-        return occ != 0;
+        if (needsHost) *needsHost = occ == 2;
+        if (occ == 2 && !needsHost)
+            fatal("IntersectP: the ray met a host-only primitive (pass needsHost and re-trace it on the CPU)");
+        return occ == 1;
     }
 
     // ---- WavefrontAggregate-shaped batches (host buffers; synchronous) -------------------
@@ -247,10 +268,10 @@ class HipKdTreeAggregate {
   public:
     HipKdTreeAggregate(const std::vector<nnbvh_prim> &prims, const std::vector<float> &verts,
                        int isectCost = 5, int traversalCost = 1, float emptyBonus = 0.5f, int maxPrims = 1,
-                       int maxDepth = -1, int device = 0) {
+                       int maxDepth = -1, int device = 0, const std::vector<float> *primBounds = nullptr) {
         nnbvh_kd_build *b = nnbvh_kd_build_create(prims.data(), (int)prims.size(), verts.data(),
-                                                  (int)(verts.size() / 3), nullptr, isectCost, traversalCost,
-                                                  emptyBonus, maxPrims, maxDepth);
+                                                  (int)(verts.size() / 3), primBounds ? primBounds->data() : nullptr,
+                                                  isectCost, traversalCost, emptyBonus, maxPrims, maxDepth);
         if (!b) {
             HipBVHAggregate::fatal("HipKdTreeAggregate: build");
             return;
@@ -278,19 +299,27 @@ class HipKdTreeAggregate {
     ~HipKdTreeAggregate() { nnbvh_kd_scene_destroy(scene_); }
 
     Bounds3f Bounds() const { return {{bounds_[0], bounds_[1], bounds_[2]}, {bounds_[3], bounds_[4], bounds_[5]}}; }
-    std::optional<HitRecord> Intersect(const Ray &ray, float tMax = std::numeric_limits<float>::infinity()) const {
+    std::optional<HitRecord> Intersect(const Ray &ray, float tMax = std::numeric_limits<float>::infinity(),
+                                       bool *needsHost = nullptr) const {
         nnbvh_ray r{{ray.o.x, ray.o.y, ray.o.z}, tMax, {ray.d.x, ray.d.y, ray.d.z}, ray.time};
         nnbvh_hit h;
         if (nnbvh_kd_intersect_closest(scene_, &r, 1, &h) != NNBVH_OK) HipBVHAggregate::fatal("kd Intersect");
+        if (needsHost) *needsHost = h.instance == -1;
+        if (h.instance == -1) {  // void: a host-only primitive or an alpha re-trace hit lay on the way
+            if (!needsHost) HipBVHAggregate::fatal("kd Intersect: the ray met a host-only primitive (pass needsHost)");
+            return {};
+        }
         if (h.prim < 0) return {};
-        return HitRecord{h.prim, h.t, h.b0, h.b1, h.b2};
+        return HitRecord{h.prim, h.t, h.b0, h.b1, h.b2, h.instance};
     }
-    bool IntersectP(const Ray &ray, float tMax = std::numeric_limits<float>::infinity()) const {
+    bool IntersectP(const Ray &ray, float tMax = std::numeric_limits<float>::infinity(), bool *needsHost = nullptr) const {
         nnbvh_ray r{{ray.o.x, ray.o.y, ray.o.z}, tMax, {ray.d.x, ray.d.y, ray.d.z}, ray.time};
         uint8_t occ = 0;
         if (nnbvh_kd_intersect_any(scene_, &r, 1, &occ, nullptr, nullptr) != NNBVH_OK)
             HipBVHAggregate::fatal("kd IntersectP");
-        return occ != 0;
+        if (needsHost) *needsHost = occ == 2;
+        if (occ == 2 && !needsHost) HipBVHAggregate::fatal("kd IntersectP: the ray met a host-only primitive (pass needsHost)");
+        return occ == 1;
     }
     void IntersectClosest(const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits) const {
         if (nnbvh_kd_intersect_closest(scene_, rays, n, hits) != NNBVH_OK) HipBVHAggregate::fatal("kd IntersectClosest");

@@ -50,6 +50,12 @@ struct Workspace {
     // grow-only staging for the host-buffer entry points
     void *d_in = nullptr, *d_out = nullptr, *d_aux0 = nullptr, *d_aux1 = nullptr;
     size_t in_bytes = 0, out_bytes = 0, aux_bytes = 0;
+    // grow-only scratch of the multi-pass entry points (IntersectShadowTr / IntersectOneRandom): ping-pong ray and
+    // hit buffers, per-item state, counters.  Per stream like the queue heads: the calls are asynchronous on their
+    // stream, so two streams must not share them
+    static constexpr int kScratch = 12;
+    void *scratch[kScratch] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[kScratch] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 }  // namespace nnbvh
@@ -87,10 +93,6 @@ struct nnbvh_scene {
     double build_ms[1] = {0};  // device build time of nnbvh_scene_create_gpu_build
     std::mutex mu;
     std::map<hipStream_t, Workspace> workspaces;
-    // grow-only scratch of the multi-pass entry points (IntersectShadowTr / IntersectOneRandom)
-    static constexpr int kScratch = 12;
-    void *scratch[kScratch] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[kScratch] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // fork/join machinery of nnbvh_trace_batches_device
     static constexpr int kSideStreams = 4;
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
@@ -629,14 +631,14 @@ void nnbvh_scene_destroy(nnbvh_scene *s) {
         void *ptrs[] = {w.queue, w.spill, w.d_in, w.d_out, w.d_aux0, w.d_aux1};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
+        for (void *p : w.scratch)
+            if (p) (void)hipFree(p);
     }
     for (int k = 0; k < nnbvh_scene::kSideStreams; ++k) {
         if (s->side[k]) (void)hipStreamDestroy(s->side[k]);
         if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]);
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-    for (void *p : s->scratch)
-        if (p) (void)hipFree(p);
     (void)hipFree(s->d_wide);  // d_prims points into the same allocation
     if (s->d_anim) (void)hipFree(s->d_anim);
     if (s->d_stats) (void)hipFree(s->d_stats);
@@ -782,7 +784,8 @@ static Workspace *workspace_for(nnbvh_scene *s, hipStream_t stream) {
     auto it = s->workspaces.find(stream);
     if (it != s->workspaces.end()) return &it->second;
     Workspace w;
-    const size_t spill_bytes = (size_t)(s->depth + 1) * (size_t)s->max_grid_threads * sizeof(uint2);
+    // an entry is spilled only when W - 1 newer ones sit above it (W >= 4): levels 0 .. depth - 3 of a lane's list
+    const size_t spill_bytes = (size_t)std::max(s->depth - 2, 1) * (size_t)s->max_grid_threads * sizeof(uint2);
     if (!hip_ok(hipMalloc((void **)&w.queue, kMaxFusedBatches * kMaxQueues * kQueueStrideWords * sizeof(unsigned)),
                 "hipMalloc(queue)"))
         return nullptr;
@@ -1245,10 +1248,10 @@ int nnbvh_triangle_interactions(const nnbvh_shading_mesh *m, const nnbvh_ray *ra
 // ---- IntersectShadowTr / IntersectOneRandom (wavefront/aggregate.cpp:70-116), media-free -------------
 // Host-driven loops of device passes; the only host round trip per pass is the 4-byte count of
 // items that go on (interface surfaces are rare: the usual shadow batch ends after its first pass).
-static bool scratch(nnbvh_scene *s, int slot, size_t bytes, void **out) {
-    if (!grow(&s->scratch[slot], &s->scratch_bytes[slot], std::max<size_t>(bytes, 16), "hipMalloc(wavefront scratch)"))
+static bool scratch(Workspace *w, int slot, size_t bytes, void **out) {
+    if (!grow(&w->scratch[slot], &w->scratch_bytes[slot], std::max<size_t>(bytes, 16), "hipMalloc(wavefront scratch)"))
         return false;
-    *out = s->scratch[slot];
+    *out = w->scratch[slot];
     return true;
 }
 
@@ -1284,9 +1287,9 @@ int nnbvh_wavefront_intersect_shadow_tr(nnbvh_scene *s, const nnbvh_shading_mesh
     if (!w) return NNBVH_ERR_DEVICE;
     const size_t n = (size_t)max_rays;
     void *raysA, *raysB, *hitsA, *hitsB, *origA, *origB, *pLight, *state, *counters, *intr;
-    if (!scratch(s, 0, n * 32, &raysA) || !scratch(s, 1, n * 32, &raysB) || !scratch(s, 2, n * 32, &hitsA) ||
-        !scratch(s, 3, n * 32, &hitsB) || !scratch(s, 4, n * 4, &origA) || !scratch(s, 5, n * 4, &origB) ||
-        !scratch(s, 6, n * 16, &pLight) || !scratch(s, 7, n, &state) || !scratch(s, 8, 64, &counters))
+    if (!scratch(w, 0, n * 32, &raysA) || !scratch(w, 1, n * 32, &raysB) || !scratch(w, 2, n * 32, &hitsA) ||
+        !scratch(w, 3, n * 32, &hitsB) || !scratch(w, 4, n * 4, &origA) || !scratch(w, 5, n * 4, &origB) ||
+        !scratch(w, 6, n * 16, &pLight) || !scratch(w, 7, n, &state) || !scratch(w, 8, 64, &counters))
         return NNBVH_ERR_DEVICE;
     int32_t *nCur = (int32_t *)counters, *nNext = nCur + 1;
     const WavefrontCount cnt{max_rays, d_size};
@@ -1317,7 +1320,7 @@ int nnbvh_wavefront_intersect_shadow_tr(nnbvh_scene *s, const nnbvh_shading_mesh
         int n_iface = 0;
         if (!read_count(nNext, stream, &n_iface)) return NNBVH_ERR_DEVICE;
         if (n_iface <= 0) break;
-        if (!scratch(s, 9, (size_t)n_iface * sizeof(nnbvh_interaction), &intr)) return NNBVH_ERR_DEVICE;
+        if (!scratch(w, 9, (size_t)n_iface * sizeof(nnbvh_interaction), &intr)) return NNBVH_ERR_DEVICE;
         if (!hip_ok(launch_triangle_interactions(m->d, raysB, nullptr, hitsB, n_iface, nNext, intr, m->n_cus * 8, stream),
                     "interaction kernel launch") ||
             !hip_ok(hipMemsetAsync(nCur, 0, 4, stream), "reset pass count") ||
@@ -1355,9 +1358,9 @@ int nnbvh_wavefront_intersect_one_random(nnbvh_scene *s, const nnbvh_shading_mes
     if (!w) return NNBVH_ERR_DEVICE;
     const size_t n = (size_t)max_items;
     void *raysA, *raysB, *hits, *origA, *origB, *pi, *rng, *weights, *counters, *intr;
-    if (!scratch(s, 0, n * 32, &raysA) || !scratch(s, 1, n * 32, &raysB) || !scratch(s, 2, n * 32, &hits) ||
-        !scratch(s, 4, n * 4, &origA) || !scratch(s, 5, n * 4, &origB) || !scratch(s, 6, n * 36, &pi) ||
-        !scratch(s, 10, n * 16, &rng) || !scratch(s, 11, n * 8, &weights) || !scratch(s, 8, 64, &counters))
+    if (!scratch(w, 0, n * 32, &raysA) || !scratch(w, 1, n * 32, &raysB) || !scratch(w, 2, n * 32, &hits) ||
+        !scratch(w, 4, n * 4, &origA) || !scratch(w, 5, n * 4, &origB) || !scratch(w, 6, n * 36, &pi) ||
+        !scratch(w, 10, n * 16, &rng) || !scratch(w, 11, n * 8, &weights) || !scratch(w, 8, 64, &counters))
         return NNBVH_ERR_DEVICE;
     int32_t *nCur = (int32_t *)counters, *nNext = nCur + 1;
     OneRandomState st{(float *)pi, (uint64_t *)rng, (float *)weights};
@@ -1377,7 +1380,7 @@ int nnbvh_wavefront_intersect_one_random(nnbvh_scene *s, const nnbvh_shading_mes
         }
         int rc = launch(s, 0, cur, active, hits, nullptr, nullptr, nullptr, stream, w, nCur);
         if (rc != NNBVH_OK) return rc;
-        if (!scratch(s, 9, (size_t)active * sizeof(nnbvh_interaction), &intr)) return NNBVH_ERR_DEVICE;
+        if (!scratch(w, 9, (size_t)active * sizeof(nnbvh_interaction), &intr)) return NNBVH_ERR_DEVICE;
         if (!hip_ok(launch_triangle_interactions(m->d, cur, nullptr, hits, active, nCur, intr, m->n_cus * 8, stream),
                     "interaction kernel launch") ||
             !hip_ok(hipMemsetAsync(nNext, 0, 4, stream), "reset pass count") ||

@@ -64,6 +64,11 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 #ifndef NNBVH_FUSED_PRIM_LOOP
 #define NNBVH_FUSED_PRIM_LOOP 0
 #endif
+// 1: the lean instances keep the ray-invariant select predicates (direction signs, kz) as wave-level masks
+// in SGPRs (trace_math.h RayMasks) instead of recomputing them per lane in every step
+#ifndef NNBVH_MASKS
+#define NNBVH_MASKS 1
+#endif
 #ifndef NNBVH_LEAN_PRIM_LOOP
 #define NNBVH_LEAN_PRIM_LOOP 1
 #endif
@@ -154,6 +159,7 @@ void trace_kernel(TraceParams p) {
     int stKind = 2;
 #endif
     RayState r;
+    RayMasks masks = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};  // lean instances: rebuilt after every refill trip
     float tMax = 0.0f;
     int visited = 0, tests = 0;
     int cur = kDone, sp = 0, base = 0;
@@ -274,7 +280,7 @@ void trace_kernel(TraceParams p) {
             if (!PATCH || !(flags & kPrimPatch)) {
                 hit = triangle_test(r, tMax, (flags & kPrimDegenerate) != 0,
                                     {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                    {s2.x, s2.y, s2.z}, x0, x1, x2, th);
+                                    {s2.x, s2.y, s2.z}, x0, x1, x2, th, (kLean && NNBVH_MASKS) ? &masks : nullptr);
                 next = slot + 3;
                 if (ALPHA && hit && (flags & kPrimAlpha)) {
                     // GeometricPrimitive::Intersect, cpu/primitive.cpp:57-70 (IntersectP takes
@@ -344,8 +350,10 @@ void trace_kernel(TraceParams p) {
         const bool swap = ((r.kz >> axis) & 1) != 0;  // dirIsNeg[axis], packed by ray_shear
         // one float per child: its entry distance, +inf if the box is missed whatever tMax is
         // (slab_entry_key) — the verdicts are then two compares against tMax
-        const float k0 = slab_entry_key(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r);
-        const float k1 = slab_entry_key(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r);
+        const float k0 = (kLean && NNBVH_MASKS) ? slab_entry_key(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, masks)
+                                                : slab_entry_key(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r);
+        const float k1 = (kLean && NNBVH_MASKS) ? slab_entry_key(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, masks)
+                                                : slab_entry_key(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r);
         const int nearRef = swap ? ref1 : ref0, farRef = swap ? ref0 : ref1;
         const float nearT = swap ? k1 : k0, farT = swap ? k0 : k1;
         visited += 1;  // the near child is entered now
@@ -556,6 +564,7 @@ void trace_kernel(TraceParams p) {
                     (tEntry < tMax);
                 cur = rootHit ? p.rootRef : kDone;
             }
+            if (kLean && NNBVH_MASKS) masks = ray_masks(r);  // some lanes carry new rays
             continue;
         }
 

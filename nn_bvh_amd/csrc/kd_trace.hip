@@ -446,7 +446,10 @@ static KdWorkspace *kd_workspace_for(nnbvh_kd_scene *s, hipStream_t stream) {
     auto it = s->workspaces.find(stream);
     if (it != s->workspaces.end()) return &it->second;
     KdWorkspace w;
-    const size_t spill_bytes = (size_t)(s->depth + 1) * (size_t)s->n_cus * 8 * kKdBlock * sizeof(float4);
+    // an entry is spilled only when W newer ones sit above it: levels 0 .. depth - W of a lane's list, at the
+    // smallest window any instance runs with
+    const size_t spill_levels = (size_t)std::max(s->depth + 1 - std::min(kKdW, kKdWLean), 1);
+    const size_t spill_bytes = spill_levels * (size_t)s->n_cus * 8 * kKdBlock * sizeof(float4);
     if (!kd_hip_ok(hipMalloc((void **)&w.queue, kKdQueues * kKdQueueStride * sizeof(unsigned)), "hipMalloc(queue)"))
         return nullptr;
     if (!kd_hip_ok(hipMalloc((void **)&w.spill, spill_bytes), "hipMalloc(spill)")) {

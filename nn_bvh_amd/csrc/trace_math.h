@@ -76,6 +76,24 @@ DEV void ray_shear(RayState &r, V3 d) {
     r.kz = (kz << 8) | (r.inv.x < 0.0f ? 1 : 0) | (r.inv.y < 0.0f ? 2 : 0) | (r.inv.z < 0.0f ? 4 : 0);
 }
 
+// Wave-level select masks of the ray-invariant predicates a step would otherwise recompute per lane and per
+// step: bit l of a mask = the predicate for lane l's ray (a ballot, held in an SGPR pair).  Valid until a
+// lane's ray changes; the lean traversal kernels rebuild them after every refill trip.
+struct RayMasks {
+    unsigned long long negX, negY, negZ;  // inv.k < 0  (dirIsNeg, aggregates.cpp:535)
+    unsigned long long k0, k1, k2;        // kz == 0 / 1 / 2  (shapes.cpp:186)
+};
+DEV RayMasks ray_masks(const RayState &r) {
+    const int kz = r.kz >> 8;
+    return {__ballot(r.inv.x < 0.0f), __ballot(r.inv.y < 0.0f), __ballot(r.inv.z < 0.0f),
+            __ballot(kz == 0), __ballot(kz == 1), __ballot(kz == 2)};
+}
+DEV float sel_m(unsigned long long m, float a, float b) {  // lane's bit of m set ? a : b — one v_cndmask, no compare
+    float out;
+    asm("v_cndmask_b32_e64 %0, %2, %1, %3" : "=v"(out) : "v"(a), "v"(b), "s"(m));
+    return out;
+}
+
 // Slab test of util/vecmath.h:1573-1608 split in two: everything that does not involve
 // the ray's tMax is evaluated here (`early` = none of the reference's early-outs fired and
 // box tMax > 0), and the entry distance is returned so that the remaining conjunct
@@ -140,21 +158,49 @@ DEV float slab_entry_key(float mnx, float mny, float mnz, float mxx, float mxy, 
     return ok ? a : __builtin_inff();
 }
 
+// slab_entry_key with the three sign tests taken from the wave's masks
+DEV float slab_entry_key(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const RayState &r,
+                         const RayMasks &m) {
+    constexpr float widen = 1.0f + 2.0f * gamma_f(3);
+    const float ax = (sel_m(m.negX, mxx, mnx) - r.o.x) * r.inv.x;
+    const float bx = (sel_m(m.negX, mnx, mxx) - r.o.x) * r.inv.x;
+    const float ay = (sel_m(m.negY, mxy, mny) - r.o.y) * r.inv.y;
+    const float by = (sel_m(m.negY, mny, mxy) - r.o.y) * r.inv.y;
+    const float az = (sel_m(m.negZ, mxz, mnz) - r.o.z) * r.inv.z;
+    const float bz = (sel_m(m.negZ, mnz, mxz) - r.o.z) * r.inv.z;
+    const float a = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
+    const float b = __builtin_fminf(__builtin_fminf(bx, by), bz) * widen;
+    const bool ok = !__builtin_isunordered(ax, bx) & (a <= b) & (b > 0.0f);
+    return ok ? a : __builtin_inff();
+}
+
 // shapes.cpp:172-273.  `degenerate` is the reference's first test
 // (LengthSquared(Cross(p2 - p0, p1 - p0)) == 0, :176-177): it depends on the triangle only and
 // is evaluated once, with the same float32 operations, when the scene is baked (kPrimDegenerate).
 DEV bool triangle_test(const RayState &r, float tMax, bool degenerate, V3 p0, V3 p1, V3 p2,
-                       float &b0, float &b1, float &b2, float &tHit) {
+                       float &b0, float &b1, float &b2, float &tHit, const RayMasks *m = nullptr) {
     if (degenerate) return false;
     V3 a = sub(p0, r.o), b = sub(p1, r.o), c = sub(p2, r.o);
-    const int kz = r.kz >> 8;
-    int kx = kz + 1;
-    if (kx == 3) kx = 0;
-    int ky = kx + 1;
-    if (ky == 3) ky = 0;
-    float p0x = sel3(a, kx), p0y = sel3(a, ky), p0z = sel3(a, kz);
-    float p1x = sel3(b, kx), p1y = sel3(b, ky), p1z = sel3(b, kz);
-    float p2x = sel3(c, kx), p2y = sel3(c, ky), p2z = sel3(c, kz);
+    float p0x, p0y, p0z, p1x, p1y, p1z, p2x, p2y, p2z;
+    if (m) {
+        // kx = kz + 1 mod 3, ky = kx + 1 mod 3: component kx is x iff kz == 2, y iff kz == 0, else z; component
+        // ky is x iff kz == 1, y iff kz == 2, else z — the same selections as sel3, from the wave's masks
+        auto px = [&](V3 v) { return sel_m(m->k2, v.x, sel_m(m->k0, v.y, v.z)); };
+        auto py = [&](V3 v) { return sel_m(m->k1, v.x, sel_m(m->k2, v.y, v.z)); };
+        auto pz = [&](V3 v) { return sel_m(m->k0, v.x, sel_m(m->k1, v.y, v.z)); };
+        p0x = px(a), p0y = py(a), p0z = pz(a);
+        p1x = px(b), p1y = py(b), p1z = pz(b);
+        p2x = px(c), p2y = py(c), p2z = pz(c);
+    } else {
+        const int kz = r.kz >> 8;
+        int kx = kz + 1;
+        if (kx == 3) kx = 0;
+        int ky = kx + 1;
+        if (ky == 3) ky = 0;
+        p0x = sel3(a, kx), p0y = sel3(a, ky), p0z = sel3(a, kz);
+        p1x = sel3(b, kx), p1y = sel3(b, ky), p1z = sel3(b, kz);
+        p2x = sel3(c, kx), p2y = sel3(c, ky), p2z = sel3(c, kz);
+    }
     const float sx = r.sx, sy = r.sy, sz = r.sz;
     p0x += sx * p0z;
     p0y += sy * p0z;

@@ -21,9 +21,11 @@ define a tree there —
 and everything is flattened depth-first into nnbvh_linear_node[] (first child = index + 1,
 axis = the split dimension), so near/far ordering and the traversal kernels work unchanged.
 
-Pinning: the reference module cannot be imported here (module-level `import tensorflow`,
-nn_BVH.py:191; no trained weights ship), so this is "parity unpinned" except for the
-3-triangle known answer of nn_test.py:48-85 (tests/test_nn_tree.py).  The candidate sweep
+Pinning: nn_BVH.py itself cannot be imported here (module-level `import tensorflow`, nn_BVH.py:191; no
+trained weights ship), so the split / greedy-SAH restatement is "parity unpinned" except for the 3-triangle
+known answer of nn_test.py:48-85 (tests/test_nn_tree.py).  What the reference's numpy-only modules DO define —
+scale_scene, the AABB accessors and get_AABB_from_primitives — is pinned bit for bit to outputs of those
+modules (tests/golden/ml_reference.npz, tests/test_ml_golden.py).  The candidate sweep
 below evaluates the same float32 expression per candidate as the TensorFlow code, with
 prefix/suffix reductions instead of O(n^2) masks.
 """
@@ -37,14 +39,38 @@ C_TRI = F(1.0)  # nn_loss.py:116
 BATCH = 8       # batch_size_gpu default, nn_BVH.py:193
 
 
-def scale_scene(P):
-    """nn_parser.py:175-250 — shift to the positive octant, divide by the largest extent.
-    P: (n, 3, 3) float64 triangle corners.  Returns a new array."""
+def scene_bounds(P):
+    """get_AABB_from_primitives (nn_AABB.py:56-91) as the reference computes it: minima start at
+    sys.float_info.max, MAXIMA at sys.float_info.min — the smallest positive double, not the most negative
+    one — so an axis whose coordinates are all below 2.2e-308 keeps that value as its maximum; no primitives
+    -> AABB(0, ..., 0).  Returns (lo[3], hi[3])."""
+    import sys
+    if len(P) == 0:
+        return np.zeros(3), np.zeros(3)
+    v = np.asarray(P, np.float64).reshape(-1, 3)
+    return np.minimum(v.min(0), sys.float_info.max), np.maximum(v.max(0), sys.float_info.min)
+
+
+def aabb_get_min(lo, axis):
+    """AABB.get_min (nn_AABB.py:21-28): axis z returns y_min."""
+    return lo[1] if axis == 2 else lo[axis]
+
+
+def aabb_get_max(hi, axis):
+    """AABB.get_max (nn_AABB.py:30-37): axis z returns y_max — the slip the greedy builder's candidate
+    padding inherits (best_sah_split)."""
+    return hi[1] if axis == 2 else hi[axis]
+
+
+def scale_scene(P, shift=0):
+    """nn_parser.py:175-250 — move the scene's minimum corner to the origin, divide by the largest extent
+    of its bounds (scene_bounds: the reference's, quirk included), add `shift`; per coordinate the
+    reference's three float64 operations in its order.  P: (n, 3, 3) triangle corners.  Returns a new array."""
     P = np.array(P, np.float64)
-    lo = P.reshape(-1, 3).min(0)
-    hi = P.reshape(-1, 3).max(0)
-    P = P + np.where(lo < 0, np.abs(lo), -lo)  # both branches move the minimum to 0
-    return P / (hi - lo).max()
+    lo, hi = scene_bounds(P)
+    P = P + np.where(lo < 0, np.abs(lo), -lo)  # both branches move the minimum to 0 (a zero minimum: no move)
+    P = P / (hi - lo).max()
+    return P + shift
 
 
 def split_mask(P, axis, pos):
@@ -93,7 +119,7 @@ def best_sah_split(P, box_min, box_max):
         rcount = (n - 1 - last).astype(F)
         # batches of 8 are padded with the parent's get_max(axis) (z returns y_max: nn_AABB.py:36-37)
         if len(cand) % BATCH:
-            fill = F(box_max[1] if axis == 2 else box_max[axis])
+            fill = F(aabb_get_max(box_max, axis))
             k = int(np.searchsorted(smids, fill, side="right"))  # prims with mid <= fill
             pad = BATCH - len(cand) % BATCH
             fl_min = pre_min[k - 1] if k > 0 else np.full(3, one)

@@ -83,6 +83,35 @@ int main() {
         if (kd.IntersectP(ray) != (occ[i] != 0)) return 13;
     }
     if (!(kd.Bounds().pMin.x <= b.pMin.x + 1e-6f)) return 14;
+    // a scene with a host-only primitive in the way: the single-ray adapters must SAY that the ray is void
+    // (ADVICE r2), in both accelerators — never answer "occluded" or "miss" for it
+    {
+        std::vector<float> v2 = {-1, -1, 0, 1, -1, 0, 0, 1, 0,    // z = 0: a triangle only the host can intersect
+                                 -1, -1, 2, 1, -1, 2, 0, 1, 2};   // z = 2: an ordinary triangle behind it
+        std::vector<nnbvh_prim> p2 = {nnbvh_prim{NNBVH_PRIM_HOST, 0, {0, 1, 2, 0}},
+                                      nnbvh_prim{NNBVH_PRIM_TRIANGLE, 1, {3, 4, 5, 0}}};
+        std::vector<float> pb = {-1, -1, 0, 1, 1, 0, /* read for the host primitive only */ 0, 0, 0, 0, 0, 0};
+        nnbvh::HipBVHAggregate a2(p2, v2, 4, "sah", 0, &pb);
+        nnbvh::HipKdTreeAggregate k2(p2, v2, 5, 1, 0.5f, 1, -1, 0, &pb);
+        nnbvh::Ray through{{0, -0.5f, -1}, {0, 0, 1}, 0}, beside{{5, 5, -1}, {0, 0, 1}, 0};
+        bool nh = false;
+        if (a2.Intersect(through, INFINITY, &nh).has_value() || !nh) return 20;
+        if (a2.IntersectP(through, INFINITY, &nh) || !nh) return 21;
+        if (k2.Intersect(through, INFINITY, &nh).has_value() || !nh) return 22;
+        if (k2.IntersectP(through, INFINITY, &nh) || !nh) return 23;
+        nh = true;
+        if (a2.Intersect(beside, INFINITY, &nh).has_value() || nh) return 24;
+        nh = true;
+        if (k2.IntersectP(beside, INFINITY, &nh) || nh) return 25;
+        // without the out-parameter a void ray is fatal
+        static int fatals = 0;
+        auto prev = nnbvh::HipBVHAggregate::fatal_handler();
+        nnbvh::HipBVHAggregate::fatal_handler() = [](const char *) { ++fatals; };
+        (void)a2.IntersectP(through);
+        (void)k2.Intersect(through);
+        nnbvh::HipBVHAggregate::fatal_handler() = prev;
+        if (fatals != 2) return 26;
+    }
     // the film: an empty film reads back as zeros (accumulation itself: tests/test_film.py)
     nnbvh::HipFilm film(0, 0, 8, 4);
     std::vector<double> px = film.Read();

@@ -137,6 +137,10 @@ def test_oracle_animated_instances_reduce_to_static_ones_at_the_time_range_ends(
     assert (h5["prim"] != h0["prim"]).mean() > 0.02  # the animated instances have moved
 
 
+# records whose nodes_visited / prim_tests differ from the libm-sinf oracle (measured: see DESIGN.md 5k)
+ANIM_COUNTER_DIFFS_MAX = 40
+
+
 @pytest.mark.gpu
 def test_device_animated_instances_equal_the_oracle():
     """The device evaluates Slerp's two per-ray sines in fp64 and rounds once; libm's sinf (the
@@ -174,7 +178,16 @@ def test_device_animated_instances_equal_the_oracle():
     m = hit & ~other_prim
     abs_t = np.abs(got["t"][m] - ref["t"][m])
     rel_t = abs_t / np.maximum(np.abs(ref["t"][m]), 1.0)   # t is a ray parameter over a 50-unit scene
+    count_diff = (got["nodes_visited"] != ref["nodes_visited"]) | (got["prim_tests"] != ref["prim_tests"])
     print(f"animated instances vs sinf oracle: {int(differ.sum())} of {n} records differ in some bit, "
-          f"{int(other_prim.sum())} in the hit primitive, max |dt| {abs_t.max():.2e}, max |dt| / max(|t|, 1) {rel_t.max():.2e}")
-    assert differ.mean() < 0.03 and other_prim.mean() < 0.001 and rel_t.max() < 1e-5
+          f"{int(other_prim.sum())} in the hit primitive / instance, {int(count_diff.sum())} in a counter, "
+          f"max |dt| {abs_t.max():.2e}, max |dt| / max(|t|, 1) {rel_t.max():.2e}")
+    # the exception covers low-order bits of t and the barycentrics ONLY: which primitive of which instance
+    # is hit never changes, and a one-ulp ray moves a box or edge verdict (hence a counter) on at most a
+    # handful of the 60 000 rays
+    assert other_prim.sum() == 0
+    assert count_diff.sum() <= ANIM_COUNTER_DIFFS_MAX, count_diff.sum()
+    only_low_bits = differ & ~count_diff
+    assert differ.mean() < 0.03 and rel_t.max() < 1e-5
+    assert np.array_equal(got["prim"][only_low_bits], ref["prim"][only_low_bits])
     agg.close()

@@ -31,8 +31,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
     assert r["value"] > 0 and r["ms_per_step"] > 0
     rf = r["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    # the record names what binds the kernel (vector-instruction issue, from committed PMC passes where this
+    # configuration has them) and never carries a fraction above 1; the SURVEY §8d algorithmic-bytes figure
+    # rides beside it as alg_hbm
+    assert rf["bound"].startswith("valu_issue") and rf["unit"] == "G wave-instr/s" and "traffic" in rf
+    assert rf["frac"] is None or (0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-2)
+    ah = rf["alg_hbm"]
+    assert ah["unit"] == "GB/s" and abs(ah["frac"] - ah["achieved"] / ah["peak"]) < 1e-3
+    assert rf["avg_launch_ms"] > 0
+    assert r["dependent_step"]["ms_per_step"] > 0 and set(r["per_class_mrays"]) >= {"primary_closest", "bounce2_closest"}
     cb = r["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert cb["matches_gpu"] is True
