@@ -473,6 +473,21 @@ typedef struct nnbvh_kd_scene nnbvh_kd_scene;
 nnbvh_kd_build *nnbvh_kd_build_create(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
                                       const float *prim_bounds, int isect_cost, int traversal_cost,
                                       float empty_bonus, int max_prims, int max_depth);
+/* The same construction on the GPU (`device`), level by level (kd_build_gpu.hip): the identical node array —
+ * split planes, child links, leaf sizes and primitiveIndices offsets do not depend on how a sort orders EQUAL
+ * (t, type) edges — with the primitives inside a multi-primitive leaf in std::stable_sort order, where
+ * nnbvh_kd_build_create leaves them as libstdc++'s std::sort does (aggregates.cpp:899-903 leaves that order
+ * to the standard library).  nnbvh_kd_build_create_stable is the host builder with that same order: the
+ * device builder's byte-for-byte checker.  No CPU fallback: without a HIP device the call fails. */
+nnbvh_kd_build *nnbvh_kd_build_create_gpu(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
+                                          const float *prim_bounds, int isect_cost, int traversal_cost,
+                                          float empty_bonus, int max_prims, int max_depth, int device);
+nnbvh_kd_build *nnbvh_kd_build_create_stable(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
+                                             const float *prim_bounds, int isect_cost, int traversal_cost,
+                                             float empty_bonus, int max_prims, int max_depth);
+/* milliseconds of the device builder: [0] on the device (upload of the bounds .. both arrays written),
+ * [1] including the download; zeros for a host build */
+int nnbvh_kd_build_timing(const nnbvh_kd_build *b, double out_ms[2]);
 const nnbvh_kd_node *nnbvh_kd_build_nodes(const nnbvh_kd_build *b, int *n_nodes);
 const int32_t *nnbvh_kd_build_prim_indices(const nnbvh_kd_build *b, int *n_indices);
 int nnbvh_kd_build_bounds(const nnbvh_kd_build *b, float out_min_max[6]);

@@ -56,7 +56,8 @@ EXPORTS = [
     "nnbvh_shading_mesh_set_instances", "nnbvh_wavefront_record_shadow_device",
     "nnbvh_film_create", "nnbvh_film_destroy", "nnbvh_film_clear", "nnbvh_film_add_samples_device",
     "nnbvh_film_pixels_device", "nnbvh_film_read", "nnbvh_film_pack_pixels_device",
-    "nnbvh_film_unpack_pixels_device", "nnbvh_kd_build_create", "nnbvh_kd_build_nodes",
+    "nnbvh_film_unpack_pixels_device", "nnbvh_kd_build_create", "nnbvh_kd_build_create_gpu",
+    "nnbvh_kd_build_create_stable", "nnbvh_kd_build_timing", "nnbvh_kd_build_nodes",
     "nnbvh_kd_build_prim_indices", "nnbvh_kd_build_bounds", "nnbvh_kd_build_depth", "nnbvh_kd_build_destroy",
     "nnbvh_kd_scene_create", "nnbvh_kd_scene_destroy", "nnbvh_kd_intersect_closest", "nnbvh_kd_intersect_any",
     "nnbvh_kd_intersect_closest_device", "nnbvh_kd_intersect_any_device",
@@ -169,6 +170,11 @@ def lib():
     L.nnbvh_film_unpack_pixels_device.argtypes = [vp, vp, i64, vp, vp]
     L.nnbvh_kd_build_create.restype = vp
     L.nnbvh_kd_build_create.argtypes = [vp, i32, vp, i32, vp, i32, i32, ctypes.c_float, i32, i32]
+    L.nnbvh_kd_build_create_stable.restype = vp
+    L.nnbvh_kd_build_create_stable.argtypes = [vp, i32, vp, i32, vp, i32, i32, ctypes.c_float, i32, i32]
+    L.nnbvh_kd_build_create_gpu.restype = vp
+    L.nnbvh_kd_build_create_gpu.argtypes = [vp, i32, vp, i32, vp, i32, i32, ctypes.c_float, i32, i32, i32]
+    L.nnbvh_kd_build_timing.argtypes = [vp, vp]
     L.nnbvh_kd_build_nodes.restype = vp
     L.nnbvh_kd_build_nodes.argtypes = [vp, ctypes.POINTER(i32)]
     L.nnbvh_kd_build_prim_indices.restype = vp

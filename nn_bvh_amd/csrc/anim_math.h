@@ -23,7 +23,7 @@ namespace nnbvh {
 // device table entry: kAnimStride = 76 floats (nnbvh_internal.h)
 // [0..2] T0, [3..5] T1, [6..9] R0 (v.xyz, w), [10..13] R1, [14..29] S0, [30..45] S1, [46] startTime,
 // [47] endTime, [48] theta, [49] SinXOverX(theta), [50..61] startTransform.mInv rows 0..2,
-// [62..73] endTransform.mInv rows 0..2, [74..75] pad
+// [62..73] endTransform.mInv rows 0..2, [74] actuallyAnimated (0 / 1), [75] pad
 
 struct Cf {
     float v, err;
@@ -62,19 +62,34 @@ DEV float sin_x_over_x_dev(float x) {  // util/math.h:340-344; sine in fp64, rou
     return (float)sin((double)x) / x;
 }
 
-// rows 0..2 of Interpolate(time).mInv; a = the instance's table entry
-DEV void anim_inverse_rows(const float *__restrict__ a, float time, float4 &r0, float4 &r1, float4 &r2) {
+// rows 0..2 of Interpolate(time).mInv (r0..r2) and, with WITH_FORWARD, of Interpolate(time).m (f0..f2: what
+// Transform::operator()(SurfaceInteraction) applies to points and vectors; AnimatedPrimitive::Intersect,
+// cpu/primitive.cpp:146-157); a = the instance's table entry, fwd = rows 0..2 of startTransform.m and of
+// endTransform.m (24 floats), read at and beyond the ends of the time range
+template <bool WITH_FORWARD>
+DEV void anim_rows(const float *__restrict__ a, const float *__restrict__ fwd, float time, float4 &r0, float4 &r1,
+                   float4 &r2, float4 &f0, float4 &f1, float4 &f2) {
     const float startTime = a[46], endTime = a[47];
     if (time <= startTime) {  // transform.cpp:1064-1065
         r0 = {a[50], a[51], a[52], a[53]};
         r1 = {a[54], a[55], a[56], a[57]};
         r2 = {a[58], a[59], a[60], a[61]};
+        if (WITH_FORWARD) {
+            f0 = {fwd[0], fwd[1], fwd[2], fwd[3]};
+            f1 = {fwd[4], fwd[5], fwd[6], fwd[7]};
+            f2 = {fwd[8], fwd[9], fwd[10], fwd[11]};
+        }
         return;
     }
     if (time >= endTime) {  // :1066-1067
         r0 = {a[62], a[63], a[64], a[65]};
         r1 = {a[66], a[67], a[68], a[69]};
         r2 = {a[70], a[71], a[72], a[73]};
+        if (WITH_FORWARD) {
+            f0 = {fwd[12], fwd[13], fwd[14], fwd[15]};
+            f1 = {fwd[16], fwd[17], fwd[18], fwd[19]};
+            f2 = {fwd[20], fwd[21], fwd[22], fwd[23]};
+        }
         return;
     }
     const float dt = (time - startTime) / (endTime - startTime);
@@ -152,6 +167,40 @@ DEV void anim_inverse_rows(const float *__restrict__ a, float time, float4 &r0, 
     r0 = {o[0], o[1], o[2], o[3]};
     r1 = {o[4], o[5], o[6], o[7]};
     r2 = {o[8], o[9], o[10], o[11]};
+    if (WITH_FORWARD) {
+        // m = (Translate.m * Rotate.m) * Scale.m (Transform::operator*, util/transform.cpp:141-143), with
+        // Rotate.m = Transpose(Rotate.mInv) (transform.h:382-383) and SquareMatrix::operator* as FMA chains
+        const float tm[16] = {1, 0, 0, tx, 0, 1, 0, ty, 0, 0, 1, tz, 0, 0, 0, 1};
+        float tr[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = __builtin_fmaf(tm[4 * i + k], rmi[4 * j + k], acc);  // rm[k][j] = rmi[j][k]
+                tr[4 * i + j] = acc;
+            }
+        float fo[12];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = __builtin_fmaf(tr[4 * i + k], S[4 * k + j], acc);
+                fo[4 * i + j] = acc;
+            }
+        f0 = {fo[0], fo[1], fo[2], fo[3]};
+        f1 = {fo[4], fo[5], fo[6], fo[7]};
+        f2 = {fo[8], fo[9], fo[10], fo[11]};
+    }
+}
+
+// rows 0..2 of Interpolate(time).mInv, the matrix Transform::ApplyInverse(Ray) reads (the traversal kernels)
+DEV void anim_inverse_rows(const float *__restrict__ a, float time, float4 &r0, float4 &r1, float4 &r2) {
+    float4 f0, f1, f2;
+    anim_rows<false>(a, nullptr, time, r0, r1, r2, f0, f1, f2);
 }
 
 }  // namespace nnbvh

@@ -206,6 +206,22 @@ static void put3(float *q, int at, const float *v) {
     q[at + 2] = v[2];
 }
 
+// one entry of the device's animation table (layout: anim_math.h)
+static float quat_angle_between_host(const float a[4], const float b[4]);
+static float sin_x_over_x_host(float x);
+static void fill_anim_entry(const nnbvh_animated_transform &a, float *t) {
+    std::memcpy(t, a.T, 24);
+    std::memcpy(t + 6, a.R, 32);
+    std::memcpy(t + 14, a.S, 128);
+    t[46] = a.start_time;
+    t[47] = a.end_time;
+    t[48] = quat_angle_between_host(a.R[0], a.R[1]);
+    t[49] = sin_x_over_x_host(t[48]);
+    std::memcpy(t + 50, a.start_inv, 48);
+    std::memcpy(t + 62, a.end_inv, 48);
+    t[74] = a.actually_animated ? 1.0f : 0.0f;
+}
+
 extern "C" {
 
 const char *nnbvh_last_error(void) { return g_error.c_str(); }
@@ -493,19 +509,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     s->device_bytes = wide_bytes + prim_bytes;
     if (animated && n_instances > 0) {
         std::vector<float> table((size_t)n_instances * kAnimStride, 0.0f);
-        for (int k = 0; k < n_instances; ++k) {
-            const nnbvh_animated_transform &a = animated[k];
-            float *t = &table[(size_t)k * kAnimStride];
-            std::memcpy(t, a.T, 24);
-            std::memcpy(t + 6, a.R, 32);
-            std::memcpy(t + 14, a.S, 128);
-            t[46] = a.start_time;
-            t[47] = a.end_time;
-            t[48] = quat_angle_between_host(a.R[0], a.R[1]);
-            t[49] = sin_x_over_x_host(t[48]);
-            std::memcpy(t + 50, a.start_inv, 48);
-            std::memcpy(t + 62, a.end_inv, 48);
-        }
+        for (int k = 0; k < n_instances; ++k) fill_anim_entry(animated[k], &table[(size_t)k * kAnimStride]);
         if (!hip_ok(hipMalloc((void **)&s->d_anim, table.size() * 4), "hipMalloc(animation table)") ||
             !hip_ok(hipMemcpy(s->d_anim, table.data(), table.size() * 4, hipMemcpyHostToDevice),
                     "hipMemcpy(animation table)")) {
@@ -1191,10 +1195,35 @@ int nnbvh_shading_mesh_set_instances(nnbvh_shading_mesh *m, const nnbvh_instance
     return NNBVH_OK;
 }
 
+int nnbvh_shading_mesh_set_instances_animated(nnbvh_shading_mesh *m, const nnbvh_instance *instances,
+                                              const nnbvh_animated_transform *animated, int n_instances) {
+    int rc = nnbvh_shading_mesh_set_instances(m, instances, n_instances);
+    if (rc != NNBVH_OK) return rc;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    for (float **p : {&m->d.anim, &m->d.animFwd}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    if (!animated || n_instances == 0) return NNBVH_OK;
+    std::vector<float> table((size_t)n_instances * kAnimStride, 0.0f), fwd((size_t)n_instances * 24);
+    for (int k = 0; k < n_instances; ++k) {
+        fill_anim_entry(animated[k], &table[(size_t)k * kAnimStride]);
+        std::memcpy(&fwd[(size_t)k * 24], animated[k].start_from, 48);       // rows 0..2 of startTransform.m
+        std::memcpy(&fwd[(size_t)k * 24 + 12], animated[k].end_from, 48);    // ... of endTransform.m
+    }
+    if (!upload(&m->d.anim, table.data(), table.size(), "shading mesh: animation table") ||
+        !upload(&m->d.animFwd, fwd.data(), fwd.size(), "shading mesh: animation table"))
+        return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
+}
+
 void nnbvh_shading_mesh_destroy(nnbvh_shading_mesh *m) {
     if (!m) return;
     DeviceGuard guard(m->device);
     if (m->d.instances) (void)hipFree(m->d.instances);
+    if (m->d.anim) (void)hipFree(m->d.anim);
+    if (m->d.animFwd) (void)hipFree(m->d.animFwd);
     void *ptrs[] = {m->d.verts, m->d.triVerts, m->d.patchVerts, m->d.normals, m->d.uvs, m->d.tangents, m->d.faceIndices, m->d.triFlags};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -16,6 +16,9 @@ struct ShadingMeshDevice {  // device pointers of a nnbvh_shading_mesh
     int nTris = 0, nVerts = 0;
     nnbvh_instance *instances = nullptr;  // optional: hits inside instances are finished on the device too
     int nInstances = 0;
+    // optional: AnimatedPrimitive instances — the traversal kernels' table (kAnimStride floats per instance,
+    // anim_math.h) and rows 0..2 of startTransform.m / endTransform.m (24 floats per instance)
+    float *anim = nullptr, *animFwd = nullptr;
     unsigned defaultFlags = 0;
 };
 

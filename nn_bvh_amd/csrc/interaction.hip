@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "interaction.h"
+#include "anim_math.h"
 
 namespace nnbvh {
 
@@ -33,12 +34,7 @@ IDEV F3 scale(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }  // Tuple3:
 IDEV float len2(F3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }   // vecmath.h:948-950
 IDEV float gamma7() { return (7.0f * 0x1p-24f) / (1.0f - 7.0f * 0x1p-24f); }  // float.h:195-197
 
-IDEV float dop(float a, float b, float c, float d) {  // math.h:569-575
-    const float cd = c * d;
-    const float diff = __builtin_fmaf(a, b, -cd);
-    const float err = __builtin_fmaf(-c, d, cd);
-    return diff + err;
-}
+// dop (DifferenceOfProducts), next_up / next_down: trace_math.h
 IDEV float sop(float a, float b, float c, float d) {  // math.h:577-583
     const float cd = c * d;
     const float s = __builtin_fmaf(a, b, cd);
@@ -69,24 +65,6 @@ IDEV F3 bary(float b0, float b1, float b2, F3 a0, F3 a1, F3 a2) {  // b0 * a0 + 
     return {(b0 * a0.x + b1 * a1.x) + b2 * a2.x, (b0 * a0.y + b1 * a1.y) + b2 * a2.y,
             (b0 * a0.z + b1 * a1.z) + b2 * a2.z};
 }
-// NextFloatUp / NextFloatDown (float.h:163-193) and Interval::FromValueAndError (math.h:829-838)
-IDEV float next_up(float v) {
-    if (__builtin_isinf(v) && v > 0.f) return v;
-    if (v == -0.f) v = 0.f;
-    unsigned ui = __float_as_uint(v);
-    if (v >= 0) ++ui;
-    else --ui;
-    return __uint_as_float(ui);
-}
-IDEV float next_down(float v) {
-    if (__builtin_isinf(v) && v < 0.f) return v;
-    if (v == 0.f) v = -0.f;
-    unsigned ui = __float_as_uint(v);
-    if (v > 0) --ui;
-    else ++ui;
-    return __uint_as_float(ui);
-}
-
 struct MeshView {
     const float *verts;
     const int32_t *triVerts, *patchVerts;
@@ -97,6 +75,7 @@ struct MeshView {
     unsigned defaultFlags;
     const nnbvh_instance *instances;
     int nInstances;
+    const float *anim, *animFwd;  // AnimatedPrimitive table + start / end forward rows, or null
 };
 
 // Transform::operator()(const SurfaceInteraction &) (util/transform.cpp:229-261) with the instance's
@@ -347,10 +326,21 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
             time = soa.time ? soa.time[i] : 0.0f;
         }
         const int instIdx = __float_as_int(h1.w) - 1;
+        nnbvh_instance xf;  // the instance's transform as this ray sees it
         if (instIdx >= 0) {
+            xf = m.instances[instIdx];
+            if (m.anim && m.anim[(long)kAnimStride * instIdx + 74] != 0.0f) {
+                // AnimatedPrimitive::Intersect (cpu/primitive.cpp:143-153): renderFromPrimitive.Interpolate(r.time),
+                // both for the ray into the instance's space and for the interaction back out of it
+                float4 r0, r1, r2, f0, f1, f2;
+                anim_rows<true>(m.anim + (long)kAnimStride * instIdx, m.animFwd + 24l * instIdx, time, r0, r1, r2, f0, f1, f2);
+                const float fr[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+                const float ir[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                for (int k = 0; k < 12; ++k) xf.render_from_prim[k] = fr[k], xf.prim_from_render[k] = ir[k];
+            }
             // TransformedPrimitive::Intersect (cpu/primitive.cpp:112-125): the shape sees the ray in the
             // instance's space, ray.d = renderFromPrimitive.ApplyInverse(r.d) (util/transform.h:401-405)
-            const float *mi = m.instances[instIdx].prim_from_render;
+            const float *mi = xf.prim_from_render;
             const F3 d = neg(wo);
             const F3 di = {mi[0] * d.x + mi[1] * d.y + mi[2] * d.z, mi[4] * d.x + mi[5] * d.y + mi[6] * d.z,
                            mi[8] * d.x + mi[9] * d.y + mi[10] * d.z};
@@ -358,7 +348,7 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
         }
         if (r.status == NNBVH_INTERACTION_PATCH) {
             patch_interaction(m, prim, h0.z, h0.w, wo, time, r);
-            if (instIdx >= 0) transform_interaction(m.instances[instIdx], r);
+            if (instIdx >= 0) transform_interaction(xf, r);
             out[i] = r;
             continue;
         }
@@ -479,7 +469,7 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
         r.dpdvs[0] = sdpdv.x, r.dpdvs[1] = sdpdv.y, r.dpdvs[2] = sdpdv.z;
         r.dndus[0] = dndu.x, r.dndus[1] = dndu.y, r.dndus[2] = dndu.z;
         r.dndvs[0] = dndv.x, r.dndvs[1] = dndv.y, r.dndvs[2] = dndv.z;
-        if (instIdx >= 0) transform_interaction(m.instances[instIdx], r);
+        if (instIdx >= 0) transform_interaction(xf, r);
         out[i] = r;
     }
 }
@@ -488,7 +478,7 @@ hipError_t launch_triangle_interactions(const ShadingMeshDevice &m, const void *
                                         const void *hits, int n, const int32_t *nDev, void *out, int maxBlocks,
                                         hipStream_t stream) {
     MeshView v{m.verts, m.triVerts, m.patchVerts, m.normals, m.uvs, m.tangents, m.faceIndices, m.triFlags, m.nTris, m.defaultFlags,
-               m.instances, m.nInstances};
+               m.instances, m.nInstances, m.anim, m.animFwd};
     nnbvh_ray_soa s;
     __builtin_memset(&s, 0, sizeof s);
     if (soa) s = *soa;

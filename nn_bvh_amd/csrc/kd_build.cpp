@@ -21,6 +21,9 @@
 #include <vector>
 
 #include "../../include/nnbvh.h"
+#include <hip/hip_runtime_api.h>
+
+#include "kd_build_gpu.h"
 #include "nnbvh_internal.h"
 
 namespace {
@@ -70,6 +73,7 @@ struct BoundEdge {                   // :781-794
 struct KdBuilder {
     int isectCost, traversalCost, maxPrims;
     float emptyBonus;
+    bool stableTies = false;  // equal (t, type) edges keep list order (std::stable_sort) instead of libstdc++'s std::sort order
     std::vector<nnbvh_kd_node> nodes;
     std::vector<int32_t> primitiveIndices;
     int maxDepthReached = 0;
@@ -116,10 +120,11 @@ struct KdBuilder {
                 edges[axis][2 * i] = BoundEdge{b.mn[axis], pn, EdgeType::Start};
                 edges[axis][2 * i + 1] = BoundEdge{b.mx[axis], pn, EdgeType::End};
             }
-            std::sort(edges[axis].begin(), edges[axis].begin() + 2 * nPrimitives,
-                      [](const BoundEdge &e0, const BoundEdge &e1) -> bool {
-                          return std::tie(e0.t, e0.type) < std::tie(e1.t, e1.type);
-                      });
+            const auto less = [](const BoundEdge &e0, const BoundEdge &e1) -> bool {
+                return std::tie(e0.t, e0.type) < std::tie(e1.t, e1.type);
+            };
+            if (stableTies) std::stable_sort(edges[axis].begin(), edges[axis].begin() + 2 * nPrimitives, less);
+            else std::sort(edges[axis].begin(), edges[axis].begin() + 2 * nPrimitives, less);
             int nBelow = 0, nAbove = (int)nPrimNums;
             for (size_t i = 0; i < 2 * nPrimNums; ++i) {
                 if (edges[axis][i].type == EdgeType::End) --nAbove;
@@ -185,19 +190,18 @@ struct nnbvh_kd_build {
     std::vector<int32_t> prim_indices;
     float bounds[6];
     int depth = 0;
+    double build_ms[2] = {0, 0};  // device builder: on the device / incl. the download
 };
 
-extern "C" {
-
-nnbvh_kd_build *nnbvh_kd_build_create(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
-                                      const float *prim_bounds, int isect_cost, int traversal_cost,
-                                      float empty_bonus, int max_prims, int max_depth) {
+// primitive bounds (Triangle::Bounds / BilinearPatch::Bounds / the caller's for host primitives), their union
+// and the depth limit of :808-809 — shared by the three builders
+static bool kd_prepare(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts, const float *prim_bounds,
+                       int *max_depth, std::vector<KBox> *primBounds, KBox *bounds) {
     if (!prims || !verts || n_prims <= 0 || n_verts <= 0) {
         nnbvh::set_error("nnbvh_kd_build_create: empty primitive or vertex array");
-        return nullptr;
+        return false;
     }
-    std::vector<KBox> primBounds((size_t)n_prims);
-    KBox bounds;
+    primBounds->resize((size_t)n_prims);
     for (int i = 0; i < n_prims; ++i) {
         const nnbvh_prim &p = prims[i];
         const int nv = nnbvh::is_triangle_kind(p.kind) ? 3 : p.kind == NNBVH_PRIM_BILINEAR_PATCH ? 4 : 0;  // kinds 4 / 5: alpha-tested triangles
@@ -205,19 +209,19 @@ nnbvh_kd_build *nnbvh_kd_build_create(const nnbvh_prim *prims, int n_prims, cons
         if (p.kind == NNBVH_PRIM_HOST) {
             if (!prim_bounds) {
                 nnbvh::set_error("nnbvh_kd_build_create: host primitives need prim_bounds");
-                return nullptr;
+                return false;
             }
             std::memcpy(b.mn, prim_bounds + 6 * (size_t)i, 12);
             std::memcpy(b.mx, prim_bounds + 6 * (size_t)i + 3, 12);
         } else if (!nv) {
             nnbvh::set_error("nnbvh_kd_build_create: unsupported primitive kind (triangles, alpha-tested triangles, patches, host primitives)");
-            return nullptr;
+            return false;
         } else {
             const float *v[4] = {nullptr, nullptr, nullptr, nullptr};
             for (int k = 0; k < nv; ++k) {
                 if (p.v[k] < 0 || p.v[k] >= n_verts) {
                     nnbvh::set_error("nnbvh_kd_build_create: vertex index out of range");
-                    return nullptr;
+                    return false;
                 }
                 v[k] = verts + 3 * (size_t)p.v[k];
             }
@@ -228,21 +232,31 @@ nnbvh_kd_build *nnbvh_kd_build_create(const nnbvh_prim *prims, int n_prims, cons
         for (int k = 0; k < 3; ++k)
             if (!std::isfinite(b.mn[k]) || !std::isfinite(b.mx[k])) {
                 nnbvh::set_error("nnbvh_kd_build_create: non-finite vertex or primitive bounds");
-                return nullptr;
+                return false;
             }
-        bounds = box_union(bounds, b);
-        primBounds[(size_t)i] = b;
+        *bounds = box_union(*bounds, b);
+        (*primBounds)[(size_t)i] = b;
     }
-    if (max_depth <= 0) max_depth = (int)std::round(8 + 1.3f * log2_int((uint64_t)n_prims));  // :808-809
-    if (max_depth > nnbvh::kMaxStack) {
+    if (*max_depth <= 0) *max_depth = (int)std::round(8 + 1.3f * log2_int((uint64_t)n_prims));  // :808-809
+    if (*max_depth > nnbvh::kMaxStack) {
         nnbvh::set_error("nnbvh_kd_build_create: max_depth above the traversal stack (64, aggregates.cpp:982)");
-        return nullptr;
+        return false;
     }
+    return true;
+}
+
+static nnbvh_kd_build *kd_build_host(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
+                                     const float *prim_bounds, int isect_cost, int traversal_cost, float empty_bonus,
+                                     int max_prims, int max_depth, bool stable_ties) {
+    std::vector<KBox> primBounds;
+    KBox bounds;
+    if (!kd_prepare(prims, n_prims, verts, n_verts, prim_bounds, &max_depth, &primBounds, &bounds)) return nullptr;
     KdBuilder kb;
     kb.isectCost = isect_cost;
     kb.traversalCost = traversal_cost;
     kb.emptyBonus = empty_bonus;
     kb.maxPrims = max_prims;
+    kb.stableTies = stable_ties;
     std::vector<BoundEdge> edges[3];
     for (int i = 0; i < 3; ++i) edges[i].resize(2 * (size_t)n_prims);
     std::vector<int> prims0((size_t)n_prims), prims1(((size_t)max_depth + 1) * (size_t)n_prims);
@@ -257,6 +271,64 @@ nnbvh_kd_build *nnbvh_kd_build_create(const nnbvh_prim *prims, int n_prims, cons
     std::memcpy(out->bounds + 3, bounds.mx, 12);
     out->depth = kb.maxDepthReached;
     return out;
+}
+
+extern "C" {
+
+nnbvh_kd_build *nnbvh_kd_build_create(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
+                                      const float *prim_bounds, int isect_cost, int traversal_cost,
+                                      float empty_bonus, int max_prims, int max_depth) {
+    return kd_build_host(prims, n_prims, verts, n_verts, prim_bounds, isect_cost, traversal_cost, empty_bonus, max_prims,
+                         max_depth, false);
+}
+
+nnbvh_kd_build *nnbvh_kd_build_create_stable(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
+                                             const float *prim_bounds, int isect_cost, int traversal_cost,
+                                             float empty_bonus, int max_prims, int max_depth) {
+    return kd_build_host(prims, n_prims, verts, n_verts, prim_bounds, isect_cost, traversal_cost, empty_bonus, max_prims,
+                         max_depth, true);
+}
+
+nnbvh_kd_build *nnbvh_kd_build_create_gpu(const nnbvh_prim *prims, int n_prims, const float *verts, int n_verts,
+                                          const float *prim_bounds, int isect_cost, int traversal_cost,
+                                          float empty_bonus, int max_prims, int max_depth, int device) {
+    std::vector<KBox> primBounds;
+    KBox bounds;
+    if (!kd_prepare(prims, n_prims, verts, n_verts, prim_bounds, &max_depth, &primBounds, &bounds)) return nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) {
+        nnbvh::set_error("nnbvh_kd_build_create_gpu: no usable HIP device (the device builder has no CPU fallback)");
+        return nullptr;
+    }
+    static_assert(sizeof(KBox) == 24, "KBox is six floats");
+    nnbvh::KdGpuResult r;
+    std::string err;
+    float b6[6];
+    std::memcpy(b6, bounds.mn, 12);
+    std::memcpy(b6 + 3, bounds.mx, 12);
+    if (!nnbvh::gpu_kd_build(reinterpret_cast<const float *>(primBounds.data()), n_prims, b6, isect_cost, traversal_cost,
+                             empty_bonus, max_prims, max_depth, device, &r, &err)) {
+        nnbvh::set_error(err);
+        return nullptr;
+    }
+    auto *out = new nnbvh_kd_build;
+    out->nodes.swap(r.nodes);
+    out->prim_indices.swap(r.prim_indices);
+    std::memcpy(out->bounds, b6, 24);
+    out->depth = r.depth;
+    out->build_ms[0] = r.device_ms;
+    out->build_ms[1] = r.total_ms;
+    return out;
+}
+
+int nnbvh_kd_build_timing(const nnbvh_kd_build *b, double out_ms[2]) {
+    if (!b || !out_ms) {
+        nnbvh::set_error("nnbvh_kd_build_timing: null argument");
+        return NNBVH_ERR_ARG;
+    }
+    out_ms[0] = b->build_ms[0];
+    out_ms[1] = b->build_ms[1];
+    return NNBVH_OK;
 }
 
 const nnbvh_kd_node *nnbvh_kd_build_nodes(const nnbvh_kd_build *b, int *n_nodes) {

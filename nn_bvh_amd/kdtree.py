@@ -9,21 +9,28 @@ import numpy as np
 from . import _lib
 from ._lib import HIT_DTYPE, KD_NODE_DTYPE, PRIM_DTYPE, RAY_DTYPE, check, ptr
 
-KdBuilt = collections.namedtuple("KdBuilt", "nodes prim_indices bounds depth")
+KdBuilt = collections.namedtuple("KdBuilt", "nodes prim_indices bounds depth build_ms", defaults=((0.0, 0.0),))
 
 
 def build_kd_tree(prims, verts, prim_bounds=None, isect_cost=5, traversal_cost=1, empty_bonus=0.5, max_prims=1,
-                  max_depth=-1):
-    """KdTreeAggregate's constructor (aggregates.cpp:798-971) on the host; defaults are those of
-    KdTreeAggregate::Create (aggregates.cpp:1152-1161)."""
+                  max_depth=-1, where="host", device=0):
+    """KdTreeAggregate's constructor (aggregates.cpp:798-971); defaults are those of KdTreeAggregate::Create
+    (aggregates.cpp:1152-1161).  where: "host" (libstdc++'s std::sort order inside multi-primitive leaves),
+    "host_stable" (std::stable_sort order) or "gpu" (the device builder: the same arrays as "host_stable")."""
     L = _lib.lib()
     prims = np.ascontiguousarray(prims, PRIM_DTYPE)
     verts = np.ascontiguousarray(verts, np.float32)
     pb = None if prim_bounds is None else np.ascontiguousarray(prim_bounds, np.float32)
-    h = L.nnbvh_kd_build_create(ptr(prims), len(prims), ptr(verts), len(verts), None if pb is None else ptr(pb),
-                                isect_cost, traversal_cost, ctypes.c_float(empty_bonus), max_prims, max_depth)
+    args = (ptr(prims), len(prims), ptr(verts), len(verts), None if pb is None else ptr(pb),
+            isect_cost, traversal_cost, ctypes.c_float(empty_bonus), max_prims, max_depth)
+    if where == "gpu":
+        h = L.nnbvh_kd_build_create_gpu(*args, device)
+    elif where == "host_stable":
+        h = L.nnbvh_kd_build_create_stable(*args)
+    else:
+        h = L.nnbvh_kd_build_create(*args)
     if not h:
-        raise _lib.NNBVHError(f"nnbvh_kd_build_create failed: {_lib.last_error()}")
+        raise _lib.NNBVHError(f"nnbvh_kd_build_create ({where}) failed: {_lib.last_error()}")
     try:
         n = ctypes.c_int()
         p = L.nnbvh_kd_build_nodes(h, ctypes.byref(n))
@@ -34,9 +41,11 @@ def build_kd_tree(prims, verts, prim_bounds=None, isect_cost=5, traversal_cost=1
         bounds = np.zeros(6, np.float32)
         check(L.nnbvh_kd_build_bounds(h, ptr(bounds)), "nnbvh_kd_build_bounds")
         depth = L.nnbvh_kd_build_depth(h)
+        ms = np.zeros(2, np.float64)
+        check(L.nnbvh_kd_build_timing(h, ptr(ms)), "nnbvh_kd_build_timing")
     finally:
         L.nnbvh_kd_build_destroy(h)
-    return KdBuilt(nodes, idx, bounds, depth)
+    return KdBuilt(nodes, idx, bounds, depth, (float(ms[0]), float(ms[1])))
 
 
 class KdTreeAggregate:

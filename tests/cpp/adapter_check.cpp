@@ -93,12 +93,16 @@ int main() {
         std::vector<float> pb = {-1, -1, 0, 1, 1, 0, /* read for the host primitive only */ 0, 0, 0, 0, 0, 0};
         nnbvh::HipBVHAggregate a2(p2, v2, 4, "sah", 0, &pb);
         nnbvh::HipKdTreeAggregate k2(p2, v2, 5, 1, 0.5f, 1, -1, 0, &pb);
-        nnbvh::Ray through{{0, -0.5f, -1}, {0, 0, 1}, 0}, beside{{5, 5, -1}, {0, 0, 1}, 0};
+        // `through` crosses the host primitive and then the triangle; `grazing` crosses the host primitive's
+        // bounds only (an any-hit ray that a device primitive occludes is occluded whatever the host one says)
+        nnbvh::Ray through{{0, -0.5f, -1}, {0, 0, 1}, 0}, grazing{{0.9f, 0.9f, -1}, {0, 0, 1}, 0},
+            beside{{5, 5, -1}, {0, 0, 1}, 0};
         bool nh = false;
         if (a2.Intersect(through, INFINITY, &nh).has_value() || !nh) return 20;
-        if (a2.IntersectP(through, INFINITY, &nh) || !nh) return 21;
+        if (a2.IntersectP(grazing, INFINITY, &nh) || !nh) return 21;
+        if (!a2.IntersectP(through, INFINITY, &nh) || nh) return 27;
         if (k2.Intersect(through, INFINITY, &nh).has_value() || !nh) return 22;
-        if (k2.IntersectP(through, INFINITY, &nh) || !nh) return 23;
+        if (k2.IntersectP(grazing, INFINITY, &nh) || !nh) return 23;
         nh = true;
         if (a2.Intersect(beside, INFINITY, &nh).has_value() || nh) return 24;
         nh = true;
@@ -107,7 +111,7 @@ int main() {
         static int fatals = 0;
         auto prev = nnbvh::HipBVHAggregate::fatal_handler();
         nnbvh::HipBVHAggregate::fatal_handler() = [](const char *) { ++fatals; };
-        (void)a2.IntersectP(through);
+        (void)a2.IntersectP(grazing);
         (void)k2.Intersect(through);
         nnbvh::HipBVHAggregate::fatal_handler() = prev;
         if (fatals != 2) return 26;
