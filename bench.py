@@ -235,7 +235,7 @@ def main():
             sys.exit("bench.py: --tree kd supports the plain step only")
         from nn_bvh_amd.aggregate import BuiltTree
         from nn_bvh_amd.kdtree import KdTreeAggregate, build_kd_tree
-        kd = build_kd_tree(prims, verts)
+        kd = build_kd_tree(prims, verts, where="gpu", device=local_rank)  # nnbvh_kd_build_create_gpu: crown in ~0.2 s
         tree = BuiltTree(kd.nodes, kd.prim_indices, kd.depth)
     elif args.tree == "nn":
         from nn_bvh_amd import nn_tree
@@ -365,10 +365,12 @@ def main():
     fused = not args.serial and kd is None
 
     def batches_of(st):
-        return [("closest", st["d_primary"].data_ptr(), st["n_primary"], st["d_hits"].data_ptr()),
-                ("closest", st["d_bounce"].data_ptr(), st["n_bounce"], st["d_bhits"].data_ptr()),
+        # the waves drain the batches in list order, so the launch's tail is the drain of the LAST batch's longest
+        # rays: the coherent primary rays go last (tools/batch_order_probe.py: 9.01 ms against 9.27 ms primary-first)
+        return [("any", st["d_shadow"].data_ptr(), st["n_shadow"], st["d_occ"].data_ptr()),
                 ("closest", st["d_bounce2"].data_ptr(), st["n_bounce2"], st["d_b2hits"].data_ptr()),
-                ("any", st["d_shadow"].data_ptr(), st["n_shadow"], st["d_occ"].data_ptr())]
+                ("closest", st["d_bounce"].data_ptr(), st["n_bounce"], st["d_bhits"].data_ptr()),
+                ("closest", st["d_primary"].data_ptr(), st["n_primary"], st["d_hits"].data_ptr())]
 
     def trace_stage(st):
         if fused:  # one launch: the wavefronts drain primary, bounce-1, bounce-2 and shadow rays one batch after the other
@@ -585,10 +587,10 @@ def main():
         root_of_bounce2 = root_of_bounce[np.nonzero(bhits["prim"] >= 0)[0]]
         perms = [sample_major(r, n_slots) for r in (root_of_primary, root_of_bounce, root_of_bounce2, root_of_bounce)]
         d_alt = [dev(a[pm]) for a, pm in zip((primary, bounce, bounce2, shadow), perms)]
-        alt = [("closest", d_alt[0].data_ptr(), n_primary, s0["d_hits"].data_ptr()),
-               ("closest", d_alt[1].data_ptr(), n_bounce, s0["d_bhits"].data_ptr()),
+        alt = [("any", d_alt[3].data_ptr(), n_shadow, s0["d_occ"].data_ptr()),
                ("closest", d_alt[2].data_ptr(), n_bounce2, s0["d_b2hits"].data_ptr()),
-               ("any", d_alt[3].data_ptr(), n_shadow, s0["d_occ"].data_ptr())]
+               ("closest", d_alt[1].data_ptr(), n_bounce, s0["d_bhits"].data_ptr()),
+               ("closest", d_alt[0].data_ptr(), n_primary, s0["d_hits"].data_ptr())]
         ms_alt = time_kernel(lambda: agg.trace_batches_device(alt, stream), reps)
         ms_own = time_kernel(lambda: trace_stage(s0), reps)
         order_probe = {

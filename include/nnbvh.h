@@ -29,6 +29,7 @@
  */
 #ifndef NNBVH_H
 #define NNBVH_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -73,6 +74,12 @@ typedef struct nnbvh_linear_node {
                                        is the geometric one); alpha-tested meshes with normals and
                                        textured alpha stay NNBVH_PRIM_HOST */
 #define NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED 5 /* same, mesh->reverseOrientation ^ transformSwapsHandedness */
+#define NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH 6  /* ... of a mesh WITH per-vertex shading normals: the ray re-traced
+                                       after a rejected hit is offset along FaceForward(n, ns) (shapes.h:
+                                       939-951, interaction.h:194-200); needs the scene's vertex normals
+                                       (nnbvh_scene_create_with_normals).  BVH scenes; inside a kd-tree
+                                       such primitives stay NNBVH_PRIM_HOST */
+#define NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED 7
 
 /* One entry of BVHAggregate::primitives: the shape handle flattened to global vertex
  * indices (Triangle{meshIndex,triIndex} -> mesh->vertexIndices[3*tri..], shapes.cpp:326-328). */
@@ -215,13 +222,27 @@ void nnbvh_transform_bounds(const float render_from_prim[12], const float in_min
 nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, const float *verts,
                                           int n_verts, const float *prim_bounds,
                                           int max_prims_in_node, int split_method, int device);
+/* nnbvh_scene_create with the meshes' per-vertex shading normals (3 floats per vertex, indexed like `verts`;
+ * TriangleMesh::n, util/mesh.h:48): read for NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH[_FLIPPED] primitives only, whose
+ * three normals are baked into the primitive stream.  normals = NULL is nnbvh_scene_create. */
+nnbvh_scene *nnbvh_scene_create_with_normals(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
+                                             int n_prims, const float *verts, const float *normals, int n_verts,
+                                             int device);
 void nnbvh_scene_destroy(nnbvh_scene *s);
 int nnbvh_scene_bounds(const nnbvh_scene *s, float out_min_max[6]);
 /* what the baked device layout looks like: [0]=interior records, [1]=prim-stream slots,
  * [2]=tree depth, [3]=device bytes, [4]=persistent grid blocks, [5]=LDS stack window */
 int nnbvh_scene_info(const nnbvh_scene *s, int64_t out[6]);
 
-/* ---- traversal, host buffers (synchronous; copies in and out) ---------------------- */
+/* ---- traversal, host buffers (synchronous; copies in and out) ----------------------
+ * What Integrator::Intersect / IntersectP callers (cpu/integrators.cpp:296-313) hand over.  The batch is
+ * traced in at most 6 chunks of at least "host_chunk" rays (option; default 2^20) that rotate over three
+ * buffer slots, with an upload, a trace and a download stream: one chunk's rays go up while the previous one
+ * is traced and the one before comes down.  Buffers
+ * the caller has pinned (hipHostMalloc, hipHostRegister, nnbvh_host_register) are read and written by the
+ * copy engines directly; pageable buffers go through pinned staging.  Results do not depend on the chunking. */
+int nnbvh_host_register(void *ptr, size_t bytes); /* pin a caller buffer (hipHostRegister) */
+int nnbvh_host_unregister(void *ptr);
 int nnbvh_intersect_closest(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits);
 /* nodes_visited / prim_tests may be NULL (then the faster non-counting kernel runs) */
 int nnbvh_intersect_any(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, uint8_t *occluded,
@@ -240,7 +261,7 @@ int nnbvh_intersect_any_device(nnbvh_scene *s, const void *d_rays, int64_t n, vo
  * are independent of each other).  Up to 4 batches of fewer than 2^28 rays each, closest-hit or
  * any-hit without counts, are traced by ONE kernel launch on `stream` (the persistent wavefronts
  * drain the batches one after the other, so the call pays one ramp-up and one drain — the
- * dependent chain of its longest ray — instead of one per batch; DESIGN.md §5g).  Other
+ * dependent chain of its longest ray — instead of one per batch; DESIGN.md §5.1).  Other
  * combinations run concurrently on internal streams forked from and joined back into `stream`.
  * Either way the call is ONE asynchronous operation on `stream`. */
 #define NNBVH_BATCH_CLOSEST 0
@@ -411,6 +432,13 @@ nnbvh_shading_mesh *nnbvh_shading_mesh_create(const float *verts, int n_verts,
  * Transform::operator()(const SurfaceInteraction &) with renderFromPrimitive (util/transform.cpp:
  * 229-261).  Without it such hits get NNBVH_INTERACTION_HOST. */
 int nnbvh_shading_mesh_set_instances(nnbvh_shading_mesh *m, const nnbvh_instance *instances, int n_instances);
+/* ... with AnimatedPrimitives among the instances (the tables given to nnbvh_scene_create_instanced_animated):
+ * a hit inside an instance whose `animated[k].actually_animated` is set is finished as
+ * AnimatedPrimitive::Intersect does (cpu/primitive.cpp:143-153) — the ray into the instance's space and the
+ * interaction back out of it both through renderFromPrimitive.Interpolate(ray.time) (util/transform.cpp:
+ * 1062-1081; the Slerp sines as in the traversal kernels).  animated = NULL: all static. */
+int nnbvh_shading_mesh_set_instances_animated(nnbvh_shading_mesh *m, const nnbvh_instance *instances,
+                                              const nnbvh_animated_transform *animated, int n_instances);
 void nnbvh_shading_mesh_destroy(nnbvh_shading_mesh *m);
 
 #define NNBVH_INTERACTION_MISS 0

@@ -45,7 +45,7 @@ assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 32
 EXPORTS = [
     "nnbvh_last_error", "nnbvh_device_count", "nnbvh_build_create", "nnbvh_build_nodes",
     "nnbvh_build_ordered_prims", "nnbvh_build_depth", "nnbvh_build_destroy",
-    "nnbvh_scene_create", "nnbvh_scene_destroy", "nnbvh_scene_bounds", "nnbvh_scene_info",
+    "nnbvh_scene_create", "nnbvh_scene_create_with_normals", "nnbvh_scene_destroy", "nnbvh_scene_bounds", "nnbvh_scene_info",
     "nnbvh_intersect_closest", "nnbvh_intersect_any", "nnbvh_intersect_closest_device",
     "nnbvh_intersect_any_device", "nnbvh_scene_set_option", "nnbvh_scene_sched_stats",
     "nnbvh_trace_batches_device", "nnbvh_scene_create_instanced", "nnbvh_transform_bounds",
@@ -53,7 +53,8 @@ EXPORTS = [
     "nnbvh_wavefront_intersect_shadow", "nnbvh_build_create_gpu", "nnbvh_build_gpu_timing",
     "nnbvh_shading_mesh_create", "nnbvh_shading_mesh_destroy", "nnbvh_triangle_interactions_device",
     "nnbvh_triangle_interactions", "nnbvh_scene_create_gpu_build",
-    "nnbvh_shading_mesh_set_instances", "nnbvh_wavefront_record_shadow_device",
+    "nnbvh_shading_mesh_set_instances", "nnbvh_shading_mesh_set_instances_animated", "nnbvh_host_register",
+    "nnbvh_host_unregister", "nnbvh_wavefront_record_shadow_device",
     "nnbvh_film_create", "nnbvh_film_destroy", "nnbvh_film_clear", "nnbvh_film_add_samples_device",
     "nnbvh_film_pixels_device", "nnbvh_film_read", "nnbvh_film_pack_pixels_device",
     "nnbvh_film_unpack_pixels_device", "nnbvh_kd_build_create", "nnbvh_kd_build_create_gpu",
@@ -104,6 +105,8 @@ def lib():
     L.nnbvh_build_destroy.argtypes = [vp]
     L.nnbvh_scene_create.restype = vp
     L.nnbvh_scene_create.argtypes = [vp, i32, vp, i32, vp, i32, i32]
+    L.nnbvh_scene_create_with_normals.restype = vp
+    L.nnbvh_scene_create_with_normals.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32]
     L.nnbvh_scene_destroy.restype = None
     L.nnbvh_scene_destroy.argtypes = [vp]
     L.nnbvh_scene_bounds.restype = i32
@@ -140,6 +143,12 @@ def lib():
     L.nnbvh_shading_mesh_create.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32]
     L.nnbvh_shading_mesh_set_instances.restype = i32
     L.nnbvh_shading_mesh_set_instances.argtypes = [vp, vp, i32]
+    L.nnbvh_host_register.restype = i32
+    L.nnbvh_host_register.argtypes = [vp, ctypes.c_size_t]
+    L.nnbvh_host_unregister.restype = i32
+    L.nnbvh_host_unregister.argtypes = [vp]
+    L.nnbvh_shading_mesh_set_instances_animated.restype = i32
+    L.nnbvh_shading_mesh_set_instances_animated.argtypes = [vp, vp, vp, i32]
     L.nnbvh_shading_mesh_destroy.restype = None
     L.nnbvh_shading_mesh_destroy.argtypes = [vp]
     L.nnbvh_triangle_interactions.restype = i32

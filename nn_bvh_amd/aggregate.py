@@ -116,12 +116,14 @@ class BVHAggregate:
         self._init(tree.nodes, tree.ordered_prims, verts, device, tree.depth)
 
     @classmethod
-    def from_tree(cls, nodes, ordered_prims, verts, device=0, instances=None, n_top_nodes=None, animated=None):
+    def from_tree(cls, nodes, ordered_prims, verts, device=0, instances=None, n_top_nodes=None, animated=None,
+                  normals=None):
         """instances (INSTANCE_DTYPE) + n_top_nodes make a two-level scene: nodes[:n_top_nodes] is
         the top-level tree, the child trees follow (see nn_bvh_amd.instancing).  animated
-        (ANIMATED_DTYPE, one per instance) turns instances into AnimatedPrimitives."""
+        (ANIMATED_DTYPE, one per instance) turns instances into AnimatedPrimitives.  normals: per-vertex
+        shading normals, needed by alpha-tested triangles of smooth meshes (prim kinds 6 / 7)."""
         self = cls.__new__(cls)
-        self._init(nodes, ordered_prims, verts, device, None, instances, n_top_nodes, animated)
+        self._init(nodes, ordered_prims, verts, device, None, instances, n_top_nodes, animated, normals)
         return self
 
     @classmethod
@@ -158,7 +160,8 @@ class BVHAggregate:
                      "depth": int(info[2]), "device_bytes": int(info[3]),
                      "grid_blocks": int(info[4]), "stack_window": int(info[5])}
 
-    def _init(self, nodes, ordered_prims, verts, device, depth, instances=None, n_top_nodes=None, animated=None):
+    def _init(self, nodes, ordered_prims, verts, device, depth, instances=None, n_top_nodes=None, animated=None,
+              normals=None):
         L = _lib.lib()
         self.nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
         self.ordered_prims = np.ascontiguousarray(ordered_prims, PRIM_DTYPE)
@@ -178,6 +181,12 @@ class BVHAggregate:
                     ptr(self.nodes), len(self.nodes), int(n_top_nodes), ptr(self.ordered_prims),
                     len(self.ordered_prims), ptr(self.verts), len(self.verts), ptr(self.instances),
                     len(self.instances), self.device)
+        elif normals is not None:
+            self.normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+            assert len(self.normals) == len(self.verts)
+            self._h = L.nnbvh_scene_create_with_normals(ptr(self.nodes), len(self.nodes), ptr(self.ordered_prims),
+                                                        len(self.ordered_prims), ptr(self.verts), ptr(self.normals),
+                                                        len(self.verts), self.device)
         else:
             self._h = L.nnbvh_scene_create(ptr(self.nodes), len(self.nodes), ptr(self.ordered_prims),
                                            len(self.ordered_prims), ptr(self.verts), len(self.verts),
@@ -216,10 +225,12 @@ class BVHAggregate:
         check(_lib.lib().nnbvh_scene_bounds(self._h, ptr(out)), "nnbvh_scene_bounds")
         return out[:3].copy(), out[3:].copy()
 
-    def Intersect(self, rays):
-        """Closest hit for a host ray batch (RAY_DTYPE) -> HIT_DTYPE array."""
+    def Intersect(self, rays, out=None):
+        """Closest hit for a host ray batch (RAY_DTYPE) -> HIT_DTYPE array (`out`: write into this array,
+        e.g. one the caller has pinned)."""
         rays = np.ascontiguousarray(rays, RAY_DTYPE)
-        hits = np.zeros(len(rays), HIT_DTYPE)
+        hits = np.zeros(len(rays), HIT_DTYPE) if out is None else out
+        assert hits.dtype == HIT_DTYPE and len(hits) == len(rays) and hits.flags.c_contiguous
         check(_lib.lib().nnbvh_intersect_closest(self._h, ptr(rays), len(rays), ptr(hits)),
               "nnbvh_intersect_closest")
         return hits

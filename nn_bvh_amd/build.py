@@ -3,7 +3,7 @@
 In-tree, explicit hipcc invocations: every source is compiled to an object under
 nn_bvh_amd/_obj/<variant>/ (in parallel, re-used while it is newer than the source and the
 headers) and the objects are linked into the .so, which travels to the GPU box with the repo
-snapshot.  -ffp-contract=off is part of the numerical contract (DESIGN.md §Exactness).
+snapshot.  -ffp-contract=off is part of the numerical contract (DESIGN.md §4).
 """
 import concurrent.futures
 import hashlib

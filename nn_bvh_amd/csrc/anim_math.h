@@ -11,7 +11,7 @@
 // the device evaluates sin in fp64 and rounds to fp32 (= the correctly rounded value; glibc's sinf
 // differs from it on roughly one input in 10^5, by one ulp).  theta = AngleBetween(R0, R1) and
 // SinXOverX(theta) depend on the transform only and are computed on the host with libm.  This is the
-// one documented tolerance exception of the traversal path (DESIGN.md §5k).
+// one documented tolerance exception of the traversal path (DESIGN.md §5.4).
 #pragma once
 #include <hip/hip_runtime.h>
 

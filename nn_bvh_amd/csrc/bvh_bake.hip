@@ -32,6 +32,10 @@ __global__ __launch_bounds__(kBk) void k_bake_slot_counts(const nnbvh_prim *__re
         atomicOr(flags, 4);
     } else if (kind == NNBVH_PRIM_HOST) atomicOr(flags, 1);
     else if (kind == NNBVH_PRIM_ALPHA_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED) atomicOr(flags, 8);
+    else if (kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH || kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED) {
+        c = 6;  // three slots of vertex normals follow the triangle's
+        atomicOr(flags, 8 | 16);
+    }
     else if (kind != NNBVH_PRIM_TRIANGLE) atomicOr(flags, 2);  // instances are not baked here
     slots[i] = c;
 }
@@ -56,6 +60,7 @@ __device__ __forceinline__ float bake_dop(float a, float b, float c, float d) {
 
 __global__ __launch_bounds__(kBk) void k_bake_stream(const nnbvh_prim *__restrict__ prims, int n,
                                                     const float *__restrict__ verts,
+                                                    const float *__restrict__ normals,
                                                     const int *__restrict__ slotOf,
                                                     const unsigned char *__restrict__ leafLast,
                                                     float4 *__restrict__ stream) {
@@ -87,6 +92,12 @@ __global__ __launch_bounds__(kBk) void k_bake_stream(const nnbvh_prim *__restric
     if (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE || p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED) {
         flags |= kPrimAlpha | (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED ? kPrimFlipN : 0u);
         alpha = __int_as_float(p.v[3]);
+    }
+    if (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH || p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED) {
+        flags |= kPrimAlpha | kPrimSmooth | (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED ? kPrimFlipN : 0u);
+        alpha = __int_as_float(p.v[3]);
+        for (int j = 0; j < 3; ++j)
+            s[3 + j] = make_float4(normals[3 * (long)p.v[j]], normals[3 * (long)p.v[j] + 1], normals[3 * (long)p.v[j] + 2], 0);
     }
     s[0] = make_float4(v[0][0], v[0][1], v[0][2], __int_as_float(p.id));
     s[1] = make_float4(v[1][0], v[1][1], v[1][2], __uint_as_float(flags));
@@ -140,7 +151,7 @@ struct Scratch {
     } while (0)
 
 bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int n_prims, const void *d_verts_,
-                    int device, BakedScene *out, std::string *error) {
+                    int device, BakedScene *out, std::string *error, const void *d_normals_) {
     const auto *dNodes = (const nnbvh_linear_node *)d_nodes_;
     const auto *dPrims = (const nnbvh_prim *)d_prims_;
     const auto *dVerts = (const float *)d_verts_;
@@ -184,6 +195,11 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
         *error = "device bake: instance primitives are baked on the host (nnbvh_scene_create_instanced)";
         return false;
     }
+    if ((flags & 16) && !d_normals_) {
+        *error = "scene_create: NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH primitives need the vertex normals "
+                 "(nnbvh_scene_create_with_normals)";
+        return false;
+    }
     if (nSlots <= 0 || nSlots >= 0x7ffffffe) {
         *error = "device bake: primitive stream exceeds 2^31 slots";
         return false;
@@ -196,7 +212,7 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
     BK_CHECK(hipMalloc(&dWide, wideBytes + (size_t)nSlots * 16 + 64), "hipMalloc(nodes + primitives)");
     dStream = (char *)dWide + wideBytes;
     BK_CHECK(hipMemsetAsync((char *)dStream + (size_t)nSlots * 16, 0, 64, stream), "memset");
-    hipLaunchKernelGGL(k_bake_stream, dim3(gp), dim3(kBk), 0, stream, dPrims, n_prims, dVerts, dSlotOf, dLeafLast,
+    hipLaunchKernelGGL(k_bake_stream, dim3(gp), dim3(kBk), 0, stream, dPrims, n_prims, dVerts, (const float *)d_normals_, dSlotOf, dLeafLast,
                        (float4 *)dStream);
     hipLaunchKernelGGL(k_bake_wide, dim3(gn), dim3(kBk), 0, stream, dNodes, n_nodes, dOrd, dSlotOf, (float4 *)dWide);
     int rootSlot = 0;

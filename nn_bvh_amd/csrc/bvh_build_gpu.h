@@ -62,7 +62,9 @@ struct BakedScene {
     int has_patches = 0;
     int has_alpha = 0;
 };
+// d_normals: per-vertex shading normals (3 floats, indexed like the vertices) or null; read for
+// NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH primitives only
 bool bake_on_device(const void *d_nodes, int n_nodes, const void *d_ordered_prims, int n_prims, const void *d_verts,
-                    int device, BakedScene *out, std::string *error);
+                    int device, BakedScene *out, std::string *error, const void *d_normals = nullptr);
 
 }  // namespace nnbvh

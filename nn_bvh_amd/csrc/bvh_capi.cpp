@@ -13,6 +13,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_trace.h"
@@ -58,6 +59,16 @@ struct Workspace {
     size_t scratch_bytes[kScratch] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// one slot of the host-buffer pipeline (nnbvh_intersect_closest / _any): device chunk buffers, events and — for
+// callers with pageable memory — pinned staging buffers
+struct HostSlot {
+    hipEvent_t ev_in = nullptr, ev_traced = nullptr, ev_out = nullptr;  // rays uploaded / chunk traced / results down
+    void *d_in = nullptr, *h_in = nullptr;
+    size_t d_in_bytes = 0, h_in_bytes = 0;
+    void *d_out[3] = {nullptr, nullptr, nullptr}, *h_out[3] = {nullptr, nullptr, nullptr};
+    size_t d_out_bytes[3] = {0, 0, 0}, h_out_bytes[3] = {0, 0, 0};
+};
+
 }  // namespace nnbvh
 
 using namespace nnbvh;
@@ -93,6 +104,10 @@ struct nnbvh_scene {
     double build_ms[1] = {0};  // device build time of nnbvh_scene_create_gpu_build
     std::mutex mu;
     std::map<hipStream_t, Workspace> workspaces;
+    static constexpr int kHostSlots = 3, kHostChunks = 6;
+    HostSlot host_slots[kHostSlots];
+    hipStream_t host_up = nullptr, host_trace = nullptr, host_down = nullptr;
+    int64_t host_chunk = 1 << 20;  // least rays per chunk of the host-buffer pipeline (at most kHostChunks chunks)
     // fork/join machinery of nnbvh_trace_batches_device
     static constexpr int kSideStreams = 4;
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
@@ -283,7 +298,8 @@ static nnbvh_scene *scene_from_baked(const BakedScene &b, int depth, int device)
 // arrays the host code below produces for two-level scenes, without the host pass over every node
 // and primitive).
 static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
-                                             int n_prims, const float *verts, int n_verts, int depth, int device) {
+                                             int n_prims, const float *verts, int n_verts, int depth, int device,
+                                             const float *normals) {
     int n_dev = nnbvh_device_count();
     if (n_dev <= 0 || device < 0 || device >= n_dev) {
         set_error("scene_create: no usable HIP device (this library has no CPU fallback)");
@@ -291,7 +307,7 @@ static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int
     }
     DeviceGuard guard(device);
     if (!guard.ok) return nullptr;
-    void *d_nodes = nullptr, *d_prims = nullptr, *d_verts = nullptr;
+    void *d_nodes = nullptr, *d_prims = nullptr, *d_verts = nullptr, *d_normals = nullptr;
     const size_t nb = (size_t)n_nodes * sizeof(nnbvh_linear_node), pbytes = (size_t)n_prims * sizeof(nnbvh_prim),
                  vb = (size_t)n_verts * 12;
     BakedScene b;
@@ -301,11 +317,14 @@ static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int
               hip_ok(hipMemcpy(d_nodes, nodes, nb, hipMemcpyHostToDevice), "hipMemcpy(tree)") &&
               hip_ok(hipMemcpy(d_prims, prims, pbytes, hipMemcpyHostToDevice), "hipMemcpy(primitives)") &&
               hip_ok(hipMemcpy(d_verts, verts, vb, hipMemcpyHostToDevice), "hipMemcpy(vertices)");
-    if (ok && !bake_on_device(d_nodes, n_nodes, d_prims, n_prims, d_verts, device, &b, &err)) {
+    if (ok && normals)
+        ok = hip_ok(hipMalloc(&d_normals, vb), "hipMalloc(normals)") &&
+             hip_ok(hipMemcpy(d_normals, normals, vb, hipMemcpyHostToDevice), "hipMemcpy(normals)");
+    if (ok && !bake_on_device(d_nodes, n_nodes, d_prims, n_prims, d_verts, device, &b, &err, d_normals)) {
         set_error(err);
         ok = false;
     }
-    for (void *p : {d_nodes, d_prims, d_verts})
+    for (void *p : {d_nodes, d_prims, d_verts, d_normals})
         if (p) (void)hipFree(p);
     return ok ? scene_from_baked(b, depth, device) : nullptr;
 }
@@ -331,7 +350,8 @@ static float sin_x_over_x_host(float x) {
 static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, int n_top_nodes,
                                  const nnbvh_prim *prims, int n_prims, const float *verts,
                                  int n_verts, const nnbvh_instance *instances, int n_instances,
-                                 int device, const nnbvh_animated_transform *animated = nullptr) {
+                                 int device, const nnbvh_animated_transform *animated = nullptr,
+                                 const float *normals = nullptr) {
     if (!nodes || !prims || !verts || n_prims <= 0 || n_verts <= 0 || n_instances < 0 ||
         (n_instances > 0 && !instances) || n_top_nodes < 1 || n_top_nodes > n_nodes) {
         set_error("scene_create: null or empty input array");
@@ -369,7 +389,15 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     for (int k = 0; k < n_prims; ++k) {
         const nnbvh_prim &p = prims[k];
         int nv, nslots;
-        if (is_triangle_kind(p.kind)) nv = nslots = 3;
+        if (is_smooth_alpha_kind(p.kind)) {
+            nv = 3;
+            nslots = 6;
+            if (!normals) {
+                set_error("scene_create: NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH primitives need the vertex normals "
+                          "(nnbvh_scene_create_with_normals)");
+                return nullptr;
+            }
+        } else if (is_triangle_kind(p.kind)) nv = nslots = 3;
         else if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) nv = nslots = 4;
         else if (p.kind == NNBVH_PRIM_HOST) {
             nv = 0;
@@ -398,7 +426,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
         return nullptr;
     }
     if (n_instances == 0)
-        return create_scene_device_bake(nodes, n_nodes, prims, n_prims, verts, n_verts, depth, device);
+        return create_scene_device_bake(nodes, n_nodes, prims, n_prims, verts, n_verts, depth, device, normals);
     // interior record numbers (global over all trees) and node refs
     std::vector<int> ord((size_t)n_nodes, -1);
     int n_interior = 0;
@@ -438,10 +466,15 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
         const int nv = is_triangle_kind(p.kind) ? 3 : 4;
         for (int j = 0; j < nv; ++j) put3(s, 4 * j, verts + 3 * (size_t)p.v[j]);
         if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) flags |= kPrimPatch;
-        if (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE || p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED) {
-            flags |= kPrimAlpha | (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED ? kPrimFlipN : 0u);
+        if (is_flat_alpha_kind(p.kind) || is_smooth_alpha_kind(p.kind)) {
+            flags |= kPrimAlpha;
+            if (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED || p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED) flags |= kPrimFlipN;
             std::memcpy(&s[11], &p.v[3], 4);  // alpha (float bit pattern) in slot 2's fourth word
             has_alpha = true;
+            if (is_smooth_alpha_kind(p.kind)) {  // the three vertex normals in slots 3..5
+                flags |= kPrimSmooth;
+                for (int j = 0; j < 3; ++j) put3(s, 12 + 4 * j, normals + 3 * (size_t)p.v[j]);
+            }
         }
         if (is_triangle_kind(p.kind) &&
             triangle_is_degenerate(verts + 3 * (size_t)p.v[0], verts + 3 * (size_t)p.v[1],
@@ -581,6 +614,12 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
     return create_scene(nodes, n_nodes, n_nodes, prims, n_prims, verts, n_verts, nullptr, 0, device);
 }
 
+nnbvh_scene *nnbvh_scene_create_with_normals(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
+                                             int n_prims, const float *verts, const float *normals, int n_verts,
+                                             int device) {
+    return create_scene(nodes, n_nodes, n_nodes, prims, n_prims, verts, n_verts, nullptr, 0, device, nullptr, normals);
+}
+
 nnbvh_scene *nnbvh_scene_create_instanced(const nnbvh_linear_node *nodes, int n_nodes,
                                           int n_top_nodes, const nnbvh_prim *prims, int n_prims,
                                           const float *verts, int n_verts,
@@ -638,6 +677,16 @@ void nnbvh_scene_destroy(nnbvh_scene *s) {
         for (void *p : w.scratch)
             if (p) (void)hipFree(p);
     }
+    for (HostSlot &sl : s->host_slots) {
+        for (void *p : {sl.d_in, sl.d_out[0], sl.d_out[1], sl.d_out[2]})
+            if (p) (void)hipFree(p);
+        for (void *p : {sl.h_in, sl.h_out[0], sl.h_out[1], sl.h_out[2]})
+            if (p) (void)hipHostFree(p);
+        for (hipEvent_t e : {sl.ev_in, sl.ev_traced, sl.ev_out})
+            if (e) (void)hipEventDestroy(e);
+    }
+    for (hipStream_t st : {s->host_up, s->host_trace, s->host_down})
+        if (st) (void)hipStreamDestroy(st);
     for (int k = 0; k < nnbvh_scene::kSideStreams; ++k) {
         if (s->side[k]) (void)hipStreamDestroy(s->side[k]);
         if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]);
@@ -745,6 +794,12 @@ int nnbvh_scene_set_option(nnbvh_scene *s, const char *key, int value) {
             return NNBVH_ERR_ARG;
         }
         s->int_repeat = value;
+    } else if (k == "host_chunk") {
+        if (value < 1024) {
+            set_error("set_option: host_chunk must be at least 1024 rays");
+            return NNBVH_ERR_ARG;
+        }
+        s->host_chunk = value;
     } else if (k == "prim_min") {
         if (value < 0 || value > 64) {
             set_error("set_option: prim_min must be 0..64");
@@ -1427,6 +1482,149 @@ int nnbvh_wavefront_intersect_one_random(nnbvh_scene *s, const nnbvh_shading_mes
     return NNBVH_OK;
 }
 
+// ---- host-buffer entry points: a pipeline of chunks -------------------------------------------------
+// What Integrator::Intersect / IntersectP callers (cpu/integrators.cpp:296-313) hand over lives in host
+// memory.  The batch is cut into chunks of up to kHostChunk rays that rotate over kHostSlots slots, each
+// with its own stream, device buffers and traversal workspace: chunk k's rays go up while chunk k-1 is
+// traced and chunk k-2's results come down.  Memory the caller has pinned (hipHostMalloc / hipHostRegister,
+// nnbvh_host_register) is read and written by the copy engines directly; pageable memory goes through pinned
+// staging buffers filled / drained by a few host threads while the other slots' GPU work is in flight.
+// Every ray's result is what the single-shot path gives (rays are independent).
+static bool host_is_pinned(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary (unregistered) host pointer: not an error
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+static void parallel_copy(void *dst, const void *src, size_t bytes) {
+    constexpr size_t kPiece = 4u << 20;
+    const int pieces = (int)std::min<size_t>(4, bytes / kPiece);
+    if (pieces < 2) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t each = (bytes / (size_t)pieces + 63) & ~(size_t)63;
+    std::thread helpers[3];
+    for (int k = 1; k < pieces; ++k) {
+        const size_t off = each * (size_t)k, len = (k == pieces - 1) ? bytes - off : each;
+        helpers[k - 1] = std::thread([=] { std::memcpy((char *)dst + off, (const char *)src + off, len); });
+    }
+    std::memcpy(dst, src, each);
+    for (int k = 1; k < pieces; ++k) helpers[k - 1].join();
+}
+
+struct HostArray {  // one per-ray output array of a call
+    void *host;
+    size_t elem;  // bytes per ray
+    bool pinned;
+};
+
+static bool slot_reserve(HostSlot &sl, size_t rays, bool need_staging_in, const HostArray *outs, int n_outs) {
+    for (hipEvent_t *e : {&sl.ev_in, &sl.ev_traced, &sl.ev_out})
+        if (!*e && !hip_ok(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate")) return false;
+    auto dev = [&](void **p, size_t *have, size_t need) {
+        if (*have >= need) return true;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        *have = 0;
+        if (!hip_ok(hipMalloc(p, need), "hipMalloc(host pipeline)")) return false;
+        *have = need;
+        return true;
+    };
+    auto pin = [&](void **p, size_t *have, size_t need) {
+        if (*have >= need) return true;
+        if (*p) (void)hipHostFree(*p);
+        *p = nullptr;
+        *have = 0;
+        if (!hip_ok(hipHostMalloc(p, need, hipHostMallocDefault), "hipHostMalloc(host pipeline)")) return false;
+        *have = need;
+        return true;
+    };
+    if (!dev(&sl.d_in, &sl.d_in_bytes, rays * 32)) return false;
+    if (need_staging_in && !pin(&sl.h_in, &sl.h_in_bytes, rays * 32)) return false;
+    for (int k = 0; k < n_outs; ++k) {
+        if (!dev(&sl.d_out[k], &sl.d_out_bytes[k], rays * outs[k].elem)) return false;
+        if (outs[k].host && !outs[k].pinned && !pin(&sl.h_out[k], &sl.h_out_bytes[k], rays * outs[k].elem)) return false;
+    }
+    return true;
+}
+
+// mode 0: outs = {hits}; mode 1 / 2: outs = {occluded, nodes_visited?, prim_tests?} (absent arrays: host = null)
+//
+// Three streams with fixed roles — upload, trace, download — and per-slot events between them.  The copies have
+// their own streams on purpose: a copy queued on the stream of the kernel it depends on is performed by a copy
+// KERNEL, which has to wait for compute units behind the next chunk's persistent trace kernel (measured: no
+// overlap at all); a copy on a stream of its own goes to a DMA engine and overlaps the trace
+// (tools/overlap_copy_probe.py: trace + upload = upload alone).
+static int host_pipeline(nnbvh_scene *s, int mode, const nnbvh_ray *rays, int64_t n, HostArray *outs, int n_outs) {
+    for (hipStream_t *st : {&s->host_up, &s->host_trace, &s->host_down})
+        if (!*st && !hip_ok(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate")) return NNBVH_ERR_DEVICE;
+    const bool rays_pinned = host_is_pinned(rays);
+    for (int k = 0; k < n_outs; ++k) outs[k].pinned = outs[k].host && host_is_pinned(outs[k].host);
+    // chunks: a launch costs ~0.5 ms of ramp-up and drain whatever its size (DESIGN.md "why launches are large"), so
+    // a batch is cut into at most kHostChunks chunks of at least host_chunk rays
+    int64_t chunk = std::max<int64_t>(s->host_chunk, (n + nnbvh_scene::kHostChunks - 1) / nnbvh_scene::kHostChunks);
+    chunk = std::min<int64_t>(chunk, n);
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    Workspace *w = workspace_for(s, s->host_trace);
+    if (!w) return NNBVH_ERR_DEVICE;
+    struct Pending {
+        int64_t first = 0, count = 0;
+        bool busy = false;
+    } pending[nnbvh_scene::kHostSlots];
+    auto drain = [&](int slot) -> bool {  // wait for the slot's chunk and hand its staged results to the caller
+        Pending &pd = pending[slot];
+        if (!pd.busy) return true;
+        HostSlot &sl = s->host_slots[slot];
+        if (!hip_ok(hipEventSynchronize(sl.ev_out), "host pipeline")) return false;
+        for (int k = 0; k < n_outs; ++k)
+            if (outs[k].host && !outs[k].pinned)
+                parallel_copy((char *)outs[k].host + (size_t)pd.first * outs[k].elem, sl.h_out[k], (size_t)pd.count * outs[k].elem);
+        pd.busy = false;
+        return true;
+    };
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int slot = (int)(c % nnbvh_scene::kHostSlots);
+        if (!drain(slot)) return NNBVH_ERR_DEVICE;
+        HostSlot &sl = s->host_slots[slot];
+        const int64_t first = c * chunk, count = std::min<int64_t>(chunk, n - first);
+        if (!slot_reserve(sl, (size_t)chunk, !rays_pinned, outs, n_outs)) return NNBVH_ERR_DEVICE;
+        const void *src = rays + first;
+        if (!rays_pinned) {
+            parallel_copy(sl.h_in, rays + first, (size_t)count * 32);
+            src = sl.h_in;
+        }
+        if (!hip_ok(hipMemcpyAsync(sl.d_in, src, (size_t)count * 32, hipMemcpyHostToDevice, s->host_up), "copy rays") ||
+            !hip_ok(hipEventRecord(sl.ev_in, s->host_up), "host pipeline") ||
+            !hip_ok(hipStreamWaitEvent(s->host_trace, sl.ev_in, 0), "host pipeline"))
+            return NNBVH_ERR_DEVICE;
+        const int rc = mode == 0 ? launch(s, 0, sl.d_in, count, sl.d_out[0], nullptr, nullptr, nullptr, s->host_trace, w)
+                                 : launch(s, mode, sl.d_in, count, nullptr, sl.d_out[0], n_outs > 1 ? sl.d_out[1] : nullptr,
+                                          n_outs > 2 ? sl.d_out[2] : nullptr, s->host_trace, w);
+        if (rc != NNBVH_OK) return rc;
+        if (!hip_ok(hipEventRecord(sl.ev_traced, s->host_trace), "host pipeline") ||
+            !hip_ok(hipStreamWaitEvent(s->host_down, sl.ev_traced, 0), "host pipeline"))
+            return NNBVH_ERR_DEVICE;
+        for (int k = 0; k < n_outs; ++k) {
+            if (!outs[k].host) continue;
+            void *dst = outs[k].pinned ? (void *)((char *)outs[k].host + (size_t)first * outs[k].elem) : sl.h_out[k];
+            if (!hip_ok(hipMemcpyAsync(dst, sl.d_out[k], (size_t)count * outs[k].elem, hipMemcpyDeviceToHost, s->host_down),
+                        "copy results"))
+                return NNBVH_ERR_DEVICE;
+        }
+        if (!hip_ok(hipEventRecord(sl.ev_out, s->host_down), "host pipeline")) return NNBVH_ERR_DEVICE;
+        pending[slot].first = first;
+        pending[slot].count = count;
+        pending[slot].busy = true;
+    }
+    for (int64_t c = n_chunks; c < n_chunks + nnbvh_scene::kHostSlots; ++c)  // oldest first
+        if (!drain((int)(c % nnbvh_scene::kHostSlots))) return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
+}
+
 int nnbvh_intersect_closest(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits) {
     if (!s || n < 0 || (n > 0 && (!rays || !hits))) {
         set_error("intersect_closest: bad argument");
@@ -1440,20 +1638,8 @@ int nnbvh_intersect_closest(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, nn
     DeviceGuard guard(s->device);
     if (!guard.ok) return NNBVH_ERR_DEVICE;
     std::lock_guard<std::mutex> lock(s->mu);  // host path: one call at a time per scene
-    Workspace *w = workspace_for(s, nullptr);
-    if (!w) return NNBVH_ERR_DEVICE;
-    const size_t bytes = (size_t)n * 32;
-    if (!grow(&w->d_in, &w->in_bytes, bytes, "hipMalloc(rays)") ||
-        !grow(&w->d_out, &w->out_bytes, bytes, "hipMalloc(hits)"))
-        return NNBVH_ERR_DEVICE;
-    if (!hip_ok(hipMemcpyAsync(w->d_in, rays, bytes, hipMemcpyHostToDevice, nullptr), "copy rays"))
-        return NNBVH_ERR_DEVICE;
-    int rc = launch(s, 0, w->d_in, n, w->d_out, nullptr, nullptr, nullptr, nullptr, w);
-    if (rc != NNBVH_OK) return rc;
-    if (!hip_ok(hipMemcpyAsync(hits, w->d_out, bytes, hipMemcpyDeviceToHost, nullptr), "copy hits") ||
-        !hip_ok(hipStreamSynchronize(nullptr), "trace kernel"))
-        return NNBVH_ERR_DEVICE;
-    return NNBVH_OK;
+    HostArray outs[1] = {{hits, 32, false}};
+    return host_pipeline(s, 0, rays, n, outs, 1);
 }
 
 int nnbvh_intersect_any(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, uint8_t *occluded,
@@ -1470,35 +1656,26 @@ int nnbvh_intersect_any(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, uint8_
     DeviceGuard guard(s->device);
     if (!guard.ok) return NNBVH_ERR_DEVICE;
     std::lock_guard<std::mutex> lock(s->mu);
-    Workspace *w = workspace_for(s, nullptr);
-    if (!w) return NNBVH_ERR_DEVICE;
     const bool counts = nodes_visited || prim_tests;
-    if (!grow(&w->d_in, &w->in_bytes, (size_t)n * 32, "hipMalloc(rays)") ||
-        !grow(&w->d_out, &w->out_bytes, (size_t)n, "hipMalloc(occluded)"))
-        return NNBVH_ERR_DEVICE;
-    if (counts) {
-        // both count arrays live in one allocation of 2 * n int32
-        size_t have = w->aux_bytes;
-        if (!grow(&w->d_aux0, &have, (size_t)n * 8, "hipMalloc(counts)")) return NNBVH_ERR_DEVICE;
-        w->aux_bytes = have;
+    // with counts the kernel writes both arrays; one the caller did not ask for stays on the device
+    HostArray outs[3] = {{occluded, 1, false}, {nodes_visited, 4, false}, {prim_tests, 4, false}};
+    return host_pipeline(s, counts ? 1 : 2, rays, n, outs, counts ? 3 : 1);
+}
+
+int nnbvh_host_register(void *ptr, size_t bytes) {
+    if (!ptr || bytes == 0) {
+        set_error("host_register: bad argument");
+        return NNBVH_ERR_ARG;
     }
-    int32_t *d_vis = counts ? (int32_t *)w->d_aux0 : nullptr;
-    int32_t *d_tst = counts ? d_vis + n : nullptr;
-    if (!hip_ok(hipMemcpyAsync(w->d_in, rays, (size_t)n * 32, hipMemcpyHostToDevice, nullptr),
-                "copy rays"))
-        return NNBVH_ERR_DEVICE;
-    int rc = launch(s, counts ? 1 : 2, w->d_in, n, nullptr, w->d_out, d_vis, d_tst, nullptr, w);
-    if (rc != NNBVH_OK) return rc;
-    bool ok = hip_ok(hipMemcpyAsync(occluded, w->d_out, (size_t)n, hipMemcpyDeviceToHost, nullptr),
-                     "copy occluded");
-    if (ok && nodes_visited)
-        ok = hip_ok(hipMemcpyAsync(nodes_visited, d_vis, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr),
-                    "copy counts");
-    if (ok && prim_tests)
-        ok = hip_ok(hipMemcpyAsync(prim_tests, d_tst, (size_t)n * 4, hipMemcpyDeviceToHost, nullptr),
-                    "copy counts");
-    ok = ok && hip_ok(hipStreamSynchronize(nullptr), "trace kernel");
-    return ok ? NNBVH_OK : NNBVH_ERR_DEVICE;
+    return hip_ok(hipHostRegister(ptr, bytes, hipHostRegisterDefault), "hipHostRegister") ? NNBVH_OK : NNBVH_ERR_DEVICE;
+}
+
+int nnbvh_host_unregister(void *ptr) {
+    if (!ptr) {
+        set_error("host_unregister: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    return hip_ok(hipHostUnregister(ptr), "hipHostUnregister") ? NNBVH_OK : NNBVH_ERR_DEVICE;
 }
 
 }  // extern "C"

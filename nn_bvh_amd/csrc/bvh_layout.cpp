@@ -139,7 +139,7 @@ bool relayout_scene(int mode, float4 **d_wide, float4 **d_prims, int *n_interior
             int64_t j = i;
             for (;;) {
                 const unsigned flags = (unsigned)__builtin_bit_cast(int, stream[(size_t)j + 1].w);
-                const int len = (flags & kPrimInstance) ? 6 : ((flags & kPrimPatch) ? 4 : 3);
+                const int len = (flags & (kPrimInstance | kPrimSmooth)) ? 6 : ((flags & kPrimPatch) ? 4 : 3);
                 j += len;
                 if ((flags & kPrimLast) || j >= ns) break;
             }

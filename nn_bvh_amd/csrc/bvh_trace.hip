@@ -42,7 +42,7 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 // MODE 2: any hit, occlusion flag only
 // MODE 3: several batches in ONE launch, each closest hit (as MODE 0) or occlusion-only any hit (as
 //         MODE 2): the batches of one wavefront iteration share a single ramp-up and a single drain
-//         (DESIGN.md §5g).  A lane's ray tag carries its batch; what differs per lane is only what a
+//         (DESIGN.md §5.1).  A lane's ray tag carries its batch; what differs per lane is only what a
 //         hit does and what is written at retire.
 //
 // Every lane is a small state machine over `cur`:
@@ -281,7 +281,7 @@ void trace_kernel(TraceParams p) {
                 hit = triangle_test(r, tMax, (flags & kPrimDegenerate) != 0,
                                     {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
                                     {s2.x, s2.y, s2.z}, x0, x1, x2, th, (kLean && NNBVH_MASKS) ? &masks : nullptr);
-                next = slot + 3;
+                next = slot + ((ALPHA && (flags & kPrimSmooth)) ? 6 : 3);
                 if (ALPHA && hit && (flags & kPrimAlpha)) {
                     // GeometricPrimitive::Intersect, cpu/primitive.cpp:57-70 (IntersectP takes
                     // the same route, :79-81): stochastic alpha test on the ray as given
@@ -295,9 +295,16 @@ void trace_kernel(TraceParams p) {
                             // shape alone: rNext = si->intr.SpawnRay(r.d), Intersect(rNext, tMax - tHit)
                             hit = false;
                             RayState rn = r;  // same direction: same reciprocals and shear
-                            rn.o = alpha_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                                        {s2.x, s2.y, s2.z}, x0, x1, x2,
-                                                        (flags & kPrimFlipN) != 0, rd);
+                            if (flags & kPrimSmooth) {  // a mesh with shading normals: offset along FaceForward(n, ns)
+                                const float4 m0 = p.prims[slot + 3], m1 = p.prims[slot + 4], m2 = p.prims[slot + 5];
+                                rn.o = alpha_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z}, x0,
+                                                            x1, x2, (flags & kPrimFlipN) != 0, rd, true, {m0.x, m0.y, m0.z},
+                                                            {m1.x, m1.y, m1.z}, {m2.x, m2.y, m2.z});
+                            } else {
+                                rn.o = alpha_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                                            {s2.x, s2.y, s2.z}, x0, x1, x2,
+                                                            (flags & kPrimFlipN) != 0, rd);
+                            }
                             tests += 1;  // Triangle::Intersect counts the re-test too
                             float y0, y1, y2, tn;
                             if (triangle_test(rn, tMax - th, (flags & kPrimDegenerate) != 0,

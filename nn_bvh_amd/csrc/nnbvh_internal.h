@@ -9,7 +9,7 @@ namespace nnbvh {
 
 void set_error(const std::string &msg);
 
-// ---- device data layout (DESIGN.md §Data layout) -----------------------------------
+// ---- device data layout -----------------------------------
 // One 64-byte record per INTERIOR node, holding both children's boxes, so that one
 // coalesced 64-B fetch decides both child visits (the reference does two dependent 32-B
 // LinearBVHNode fetches for the same decisions).  Records are numbered in the order
@@ -52,9 +52,19 @@ constexpr uint32_t kPrimFlipN = 64u;
 // instance record of an AnimatedPrimitive: the inverse matrix is interpolated per ray from the
 // animation table (anim_math.h) instead of read from slots 2..4
 constexpr uint32_t kPrimAnimated = 128u;
+// alpha-tested triangle of a mesh WITH per-vertex shading normals: three more slots {n0,0} {n1,0} {n2,0} follow
+// (the re-trace after a rejected hit offsets along FaceForward(n, ns), shapes.h:939-951)
+constexpr uint32_t kPrimSmooth = 256u;
 constexpr int kAnimStride = 76;  // floats per entry of the animation table (layout: anim_math.h)
 inline bool is_triangle_kind(int kind) {
-    return kind == NNBVH_PRIM_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED;
+    return kind == NNBVH_PRIM_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED ||
+           kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH || kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED;
+}
+inline bool is_smooth_alpha_kind(int kind) {
+    return kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH || kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED;
+}
+inline bool is_flat_alpha_kind(int kind) {
+    return kind == NNBVH_PRIM_ALPHA_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED;
 }
 
 constexpr int kMaxStack = 64;  // the reference's nodesToVisit[64], aggregates.cpp:538

@@ -104,12 +104,16 @@ DEV void spawn_ray_to(V3 lo, V3 hi, V3 n, V3 pTo, V3 &o, V3 &d) {
 }
 
 // Origin of the ray GeometricPrimitive::Intersect traces on after an alpha-rejected triangle hit
-// (cpu/primitive.cpp:64-66: rNext = si->intr.SpawnRay(r.d)) for a triangle of a mesh WITHOUT
-// per-vertex shading normals: Triangle::InteractionFromIntersection (shapes.h:884-1010) gives
+// (cpu/primitive.cpp:64-66: rNext = si->intr.SpawnRay(r.d)): Triangle::InteractionFromIntersection
+// (shapes.h:884-1010) gives
 //   pHit = b0 p0 + b1 p1 + b2 p2, pError = gamma(7) (|b0 p0| + |b1 p1| + |b2 p2|), pi = Point3fi(pHit, pError)
 //   n = Normalize(Cross(p0 - p2, p1 - p2)), negated under reverseOrientation ^ transformSwapsHandedness
 // and Interaction::SpawnRay(d) = OffsetRayOrigin(pi, n, d) (interaction.h:98-100, ray.h:75-92).
-DEV V3 alpha_retrace_origin(V3 p0, V3 p1, V3 p2, float b0, float b1, float b2, bool flip, V3 d) {
+// smooth = the mesh has per-vertex shading normals n0 n1 n2: the interaction's normal is then
+//   FaceForward(n, ns), ns = Normalize(b0 n0 + b1 n1 + b2 n2) (or n where that sum is zero),
+// shapes.h:939-951 + SetShadingGeometry(..., orientationIsAuthoritative = true), interaction.h:194-200
+DEV V3 alpha_retrace_origin(V3 p0, V3 p1, V3 p2, float b0, float b1, float b2, bool flip, V3 d, bool smooth = false,
+                            V3 n0 = {0, 0, 0}, V3 n1 = {0, 0, 0}, V3 n2 = {0, 0, 0}) {
     constexpr float g7 = gamma_f(7);
     const V3 ph = {(b0 * p0.x + b1 * p1.x) + b2 * p2.x, (b0 * p0.y + b1 * p1.y) + b2 * p2.y,
                    (b0 * p0.z + b1 * p1.z) + b2 * p2.z};
@@ -125,6 +129,18 @@ DEV V3 alpha_retrace_origin(V3 p0, V3 p1, V3 p2, float b0, float b1, float b2, b
     const float len = __builtin_sqrtf(len2(c));  // Normalize: v / Length(v)
     V3 n = {c.x / len, c.y / len, c.z / len};
     if (flip) n = {-n.x, -n.y, -n.z};
+    if (smooth) {
+        V3 ns = {(b0 * n0.x + b1 * n1.x) + b2 * n2.x, (b0 * n0.y + b1 * n1.y) + b2 * n2.y,
+                 (b0 * n0.z + b1 * n1.z) + b2 * n2.z};
+        const float l2 = len2(ns);
+        if (l2 > 0) {
+            const float l = __builtin_sqrtf(l2);
+            ns = {ns.x / l, ns.y / l, ns.z / l};
+        } else {
+            ns = n;
+        }
+        if (dot_n(n, ns) < 0.f) n = {-n.x, -n.y, -n.z};  // n = FaceForward(n, shading.n)
+    }
     return offset_ray_origin(lo, hi, n, d);
 }
 

@@ -34,12 +34,20 @@ class ShadingMesh:
         if not self._h:
             raise NNBVHError("nnbvh_shading_mesh_create: " + _lib.last_error())
 
-    def set_instances(self, instances):
+    def set_instances(self, instances, animated=None):
         """The scene's instance table (INSTANCE_DTYPE): hits inside instances are then finished on the
-        device (TransformedPrimitive::Intersect's transform of the interaction)."""
+        device (TransformedPrimitive::Intersect's transform of the interaction).  animated: the
+        ANIMATED_DTYPE table of the same scene — hits inside AnimatedPrimitives then use
+        renderFromPrimitive.Interpolate(ray.time) (cpu/primitive.cpp:143-153)."""
         inst = np.ascontiguousarray(instances, _lib.INSTANCE_DTYPE)
-        check(_lib.lib().nnbvh_shading_mesh_set_instances(self._h, ptr(inst), len(inst)),
-              "nnbvh_shading_mesh_set_instances")
+        if animated is None:
+            check(_lib.lib().nnbvh_shading_mesh_set_instances(self._h, ptr(inst), len(inst)),
+                  "nnbvh_shading_mesh_set_instances")
+            return
+        anim = np.ascontiguousarray(animated, _lib.ANIMATED_DTYPE)
+        assert len(anim) == len(inst)
+        check(_lib.lib().nnbvh_shading_mesh_set_instances_animated(self._h, ptr(inst), ptr(anim), len(inst)),
+              "nnbvh_shading_mesh_set_instances_animated")
 
     def close(self):
         if getattr(self, "_h", None):

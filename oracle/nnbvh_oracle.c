@@ -621,7 +621,7 @@ static void instance_minv(const orc_instance *in, int index, float out12[12]) {
 /* ---- primitive dispatch (cpu/primitive.cpp:24-32 -> shapes.cpp:320-358, 1131-1156) --- */
 static inline int prim_test(const orc_prim *p, const float *verts, const float o[3],
                             const float d[3], float tmax, float res[4]) {
-    if (p->kind == 0 || p->kind == 4 || p->kind == 5) {
+    if (p->kind == 0 || (p->kind >= 4 && p->kind <= 7)) {
         return orc_triangle(o, d, tmax, verts + 3 * (size_t)p->v[0], verts + 3 * (size_t)p->v[1],
                             verts + 3 * (size_t)p->v[2], res);
     } else {
@@ -640,7 +640,9 @@ static inline int prim_test(const orc_prim *p, const float *verts, const float o
 
 /* ---- GeometricPrimitive::Intersect with a constant alpha, cpu/primitive.cpp:50-77 ------------- */
 /* prim kinds 4 / 5: a triangle (mesh without per-vertex normals; 5 = flipped orientation) behind a
- * GeometricPrimitive whose alpha texture evaluates to the constant in v[3] (float bit pattern).
+ * GeometricPrimitive whose alpha texture evaluates to the constant in v[3] (float bit pattern);
+ * kinds 6 / 7: the same for a mesh WITH per-vertex shading normals (orc_set_vertex_normals): the interaction
+ * the re-traced ray is spawned from then carries n = FaceForward(n, ns) (shapes.h:939-951).
  * Every Triangle::Intersect call counts in nTriTests, the recursive ones too. */
 int orc_triangle_interaction(const float p9[9], const float *uv6, const float *n9, const float *s9,
                              int flip_normal, const float b[3], const float wo[3], float time,
@@ -654,6 +656,9 @@ void orc_offset_ray_origin(const float lo[3], const float hi[3], const float n[3
  * degenerate rays (NaN / zero direction, NaN tHit) make the second test succeed, and then the reference
  * recurses without bound; the library's contract for that case is "the record is void, the caller
  * re-traces the ray" (*host_io = 1), and this restatement follows it instead of overflowing the stack. */
+static const float *g_vertex_normals = NULL; /* 3 floats per vertex, indexed like verts; kinds 6 / 7 read it */
+void orc_set_vertex_normals(const float *normals) { g_vertex_normals = normals; }
+
 static int alpha_intersect(const orc_prim *p, const float *verts, const float o[3], const float d[3],
                            float tmax, float res[4], int *tests, int *host_io) {
     float r[4];
@@ -665,11 +670,14 @@ static int alpha_intersect(const orc_prim *p, const float *verts, const float o[
         const float u = (a <= 0) ? 1.f : orc_hash_float_6f(o, d); /* :60 */
         if (u > a) {
             /* :63-69 ignore this intersection and trace a new ray: rNext = si->intr.SpawnRay(r.d) */
-            float p9[9], wo[3] = {-d[0], -d[1], -d[2]}, rec[44], on[3], rn[4];
+            float p9[9], n9[9], wo[3] = {-d[0], -d[1], -d[2]}, rec[44], on[3], rn[4];
+            const int smooth = (p->kind == 6 || p->kind == 7) && g_vertex_normals;
             memcpy(p9, verts + 3 * (size_t)p->v[0], 12);
             memcpy(p9 + 3, verts + 3 * (size_t)p->v[1], 12);
             memcpy(p9 + 6, verts + 3 * (size_t)p->v[2], 12);
-            orc_triangle_interaction(p9, NULL, NULL, NULL, p->kind == 5, r, wo, 0.0f, 0, rec);
+            if (smooth)
+                for (int j = 0; j < 3; ++j) memcpy(n9 + 3 * j, g_vertex_normals + 3 * (size_t)p->v[j], 12);
+            orc_triangle_interaction(p9, NULL, smooth ? n9 : NULL, NULL, p->kind == 5 || p->kind == 7, r, wo, 0.0f, 0, rec);
             orc_offset_ray_origin(rec + 38, rec + 41, rec + 11, d, on);
             ++*tests; /* Triangle::Intersect counts the re-test too */
             if (prim_test(p, verts, on, d, tmax - r[3], rn)) *host_io = 1;
@@ -722,7 +730,7 @@ static void closest_tree(const orc_node *nodes, const orc_prim *prims, const flo
                         continue;
                     }
                     int primHit;
-                    if (p->kind == 4 || p->kind == 5) {
+                    if (p->kind >= 4 && p->kind <= 7) {
                         primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests, host_io);
                     } else {
                         ++tests;
@@ -809,7 +817,7 @@ static int any_tree(const orc_node *nodes, const orc_prim *prims, const float *v
                         continue;
                     }
                     int primHit; /* GeometricPrimitive::IntersectP with alpha = Intersect(...).has_value(), :79-81 */
-                    if (p->kind == 4 || p->kind == 5) {
+                    if (p->kind >= 4 && p->kind <= 7) {
                         primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests, host_io);
                     } else {
                         ++tests;
@@ -1711,7 +1719,7 @@ static void kd_one(const orc_kd_node *nodes, const int32_t *prim_indices, const 
                         continue;
                     }
                     int primHit; /* GeometricPrimitive with a constant alpha: cpu/primitive.cpp:57-70, 79-81 */
-                    if (p->kind == 4 || p->kind == 5) {
+                    if (p->kind >= 4 && p->kind <= 7) {
                         primHit = alpha_intersect(p, verts, o, d, rayTMax, r, &tests, &host);
                     } else {
                         ++tests;

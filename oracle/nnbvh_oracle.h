@@ -169,6 +169,9 @@ void orc_anim_interpolate(const orc_anim *a, float time, float m[16], float minv
 /* 0 (default): Slerp's per-ray sines with libm's sinf, as the reference; 1: evaluated in double and
  * rounded once, as the device does (its documented tolerance exception) */
 void orc_set_sin_mode(int mode);
+/* per-vertex shading normals (3 floats per vertex, indexed like verts) for prim kinds 6 / 7 (alpha-tested
+ * triangles of smooth meshes); NULL = none.  The pointer is kept: it must outlive the traces that use it. */
+void orc_set_vertex_normals(const float *normals);
 void orc_anim_interpolate_batch(const orc_anim *a, const float *time, int n, float *out32);
 /* two-level traversal with AnimatedPrimitive instances (cpu/primitive.cpp:133-158): anims[k] belongs to
  * instances[k]; entries with actually_animated == 0 are TransformedPrimitives */

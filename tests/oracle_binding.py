@@ -325,3 +325,13 @@ def any_hit_anim(nodes, prims, verts, instances, anims, rays, nthreads=1):
 def set_sin_mode(mode):
     """0: Slerp's per-ray sines with libm's sinf (the reference); 1: fp64 sine rounded once (the device)."""
     lib().orc_set_sin_mode(ctypes.c_int(mode))
+
+
+_normals_keepalive = None
+
+
+def set_vertex_normals(normals):
+    """Per-vertex shading normals for prim kinds 6 / 7 (alpha-tested triangles of smooth meshes); None = none."""
+    global _normals_keepalive
+    _normals_keepalive = None if normals is None else np.ascontiguousarray(normals, np.float32)
+    lib().orc_set_vertex_normals(None if normals is None else _p(_normals_keepalive))

@@ -126,3 +126,69 @@ def test_device_alpha_inside_instances():
     eo, ev, et = ob.any_hit_inst(nodes, aprims, verts, instances, rays, 4)
     assert np.array_equal(occ, eo) and np.array_equal(vis, ev) and np.array_equal(tst, et)
     agg.close()
+
+
+def smooth_alpha_scene(seed=21, n=5000):
+    """alpha_scene with two thirds of the alpha-tested triangles on a 'smooth mesh' (kinds 6 / 7) and random
+    per-vertex shading normals — half of them pointing to the other side of the triangle than its geometric
+    normal, so that FaceForward(n, ns) flips the offset direction, and a few zero normals (ns falls back to n)."""
+    verts, prims, alpha, kinds = alpha_scene(seed, n)
+    rng = np.random.default_rng(seed + 7)
+    prims = prims.copy()
+    smooth = (kinds != 0) & (rng.random(len(prims)) < 0.67)
+    prims["kind"] = np.where(smooth, kinds + 2, kinds)   # 4 -> 6, 5 -> 7
+    normals = rng.normal(size=(len(verts), 3)).astype(np.float32)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    normals[rng.random(len(verts)) < 0.02] = 0
+    return verts, prims, normals, alpha, prims["kind"].copy()
+
+
+def test_oracle_smooth_alpha_offsets_along_the_face_forwarded_normal():
+    verts, prims, normals, alpha, kinds = smooth_alpha_scene()
+    tree = build_tree(prims, verts)
+    rays = scene.random_rays(20000, verts.min(0) - 1, verts.max(0) + 1, 7)
+    try:
+        ob.set_vertex_normals(normals)
+        h = ob.closest(tree.nodes, tree.ordered_prims, verts, rays)
+        # the same scene with every normal on the geometric normal's side gives the flat kinds' records ...
+        flat = prims.copy()
+        flat["kind"] = np.where(kinds >= 6, kinds - 2, kinds)
+        tf = build_tree(flat, verts)
+        assert tf.nodes.tobytes() == tree.nodes.tobytes()  # kinds 6 / 7 build like triangles
+        hf = ob.closest(tf.nodes, tf.ordered_prims, verts, rays)
+    finally:
+        ob.set_vertex_normals(None)
+    # ... and which primitive is hit never depends on the normals (the re-trace against the same planar
+    # triangle misses whichever side it is offset to); only void flags could differ, and there are none
+    assert (h["instance"] == -1).sum() == 0 and h.tobytes() == hf.tobytes()
+    assert ((kinds[np.maximum(h["prim"], 0)] >= 6) & (h["prim"] >= 0)).sum() > 500
+    # without normals the smooth kinds cannot be evaluated by the library; the oracle then treats them as flat
+
+
+@pytest.mark.gpu
+def test_device_smooth_alpha_equals_oracle():
+    """NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH: the re-trace origin is offset along FaceForward(n, ns) (shapes.h:939-951).
+    Records and counters bit-equal to the oracle; and the offset origin itself is exercised through rays that
+    start exactly ON an alpha triangle's re-trace path: the re-trace origins of flat and smooth kinds differ."""
+    from nn_bvh_amd import BVHAggregate
+    from nn_bvh_amd._lib import NNBVHError
+    verts, prims, normals, alpha, kinds = smooth_alpha_scene(23, 6000)
+    tree = build_tree(prims, verts)
+    rays = np.concatenate([scene.random_rays(60000, verts.min(0) - 1, verts.max(0) + 1, 8),
+                           scene.random_rays(10000, verts.min(0), verts.max(0), 10, tmax=0.6)])
+    with pytest.raises(NNBVHError, match="normals"):
+        BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals)
+    got = agg.Intersect(rays)
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    try:
+        ob.set_vertex_normals(normals)
+        exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, 4)
+        eo, ev, et = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, 4)
+    finally:
+        ob.set_vertex_normals(None)
+    assert got.tobytes() == exp.tobytes()
+    assert np.array_equal(occ, eo) and np.array_equal(vis, ev) and np.array_equal(tst, et)
+    assert np.array_equal(agg.IntersectP(rays), eo)
+    assert ((kinds[np.maximum(exp["prim"], 0)] >= 6) & (exp["prim"] >= 0)).mean() > 0.1
+    agg.close()

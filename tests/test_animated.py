@@ -137,7 +137,7 @@ def test_oracle_animated_instances_reduce_to_static_ones_at_the_time_range_ends(
     assert (h5["prim"] != h0["prim"]).mean() > 0.02  # the animated instances have moved
 
 
-# records whose nodes_visited / prim_tests differ from the libm-sinf oracle (measured: see DESIGN.md 5k)
+# records whose nodes_visited / prim_tests differ from the libm-sinf oracle (measured: see DESIGN.md §5.4)
 ANIM_COUNTER_DIFFS_MAX = 0  # measured: 325 of 60 000 records differ, none in a counter
 
 
@@ -148,7 +148,7 @@ def test_device_animated_instances_equal_the_oracle():
     input in a hundred.  The kernel must therefore be BIT-EQUAL to the oracle run with the same sine
     (everything else of Interpolate / ApplyInverse / traversal being the reference's arithmetic), and
     against the reference-faithful oracle (sinf) only low-order bits of t / barycentrics of a small
-    fraction of rays may move: the documented tolerance exception (DESIGN.md 5k)."""
+    fraction of rays may move: the documented tolerance exception (DESIGN.md §5.4)."""
     from nn_bvh_amd import BVHAggregate, scene
     verts, prims, _, _, _, _, anims, oa, placements = animated_scene(4, 36)
     nodes, aprims, instances, n_top = rebuild_with_motion_bounds(verts, prims, placements, anims, oa)

@@ -496,3 +496,38 @@ def test_device_entry_points_are_hip_graph_capturable():
     torch.cuda.synchronize()
     assert torch.equal(d_hits, eager_hits) and torch.equal(d_occ, eager_occ)
     agg.close()
+
+
+@pytest.mark.gpu
+def test_host_buffer_pipeline_is_independent_of_chunking_and_pinning():
+    """nnbvh_intersect_closest / _any cut a host batch into chunks that rotate over three streams; buffers the
+    caller pinned are DMA'd directly, pageable ones are staged.  Whatever the chunk size (13 chunks, ragged last
+    chunk, one chunk) and wherever the buffers live, the records are the oracle's."""
+    # 52 048 rays: host_chunk 4096 -> 6 chunks of 8 675; 20 000 -> 3 chunks, the last ragged; 2^20 -> one chunk
+    import ctypes
+    from nn_bvh_amd import _lib
+    verts, prims = ss.random_soup(4000, 300, 41)
+    tree = build_tree(prims, verts)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+    rays = np.concatenate([scene.random_rays(50_000, verts.min(0) - 2, verts.max(0) + 2, 42), ss.edge_case_rays(verts, prims, 43)])
+    exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, nthreads=8)
+    eocc, evis, etst = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, nthreads=8)
+    L = _lib.lib()
+    pinned_rays, pinned_hits = rays.copy(), np.zeros(len(rays), exp.dtype)
+    for a in (pinned_rays, pinned_hits):
+        assert L.nnbvh_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes) == 0, _lib.last_error()
+    try:
+        for chunk in (4096, 20000, 1 << 20):
+            agg.set_option("host_chunk", chunk)
+            assert agg.Intersect(rays).tobytes() == exp.tobytes(), f"pageable, chunk {chunk}"
+            pinned_hits[:] = 0
+            assert agg.Intersect(pinned_rays, pinned_hits).tobytes() == exp.tobytes(), f"pinned, chunk {chunk}"
+            occ, vis, tst = agg.IntersectP(rays, counts=True)
+            assert np.array_equal(occ, eocc) and np.array_equal(vis, evis) and np.array_equal(tst, etst)
+            assert np.array_equal(agg.IntersectP(pinned_rays), eocc)
+        # a single ray (the per-ray adapter's shape) and an empty batch
+        assert agg.Intersect(rays[:1]).tobytes() == exp[:1].tobytes() and len(agg.Intersect(rays[:0])) == 0
+    finally:
+        for a in (pinned_rays, pinned_hits):
+            L.nnbvh_host_unregister(ctypes.c_void_p(a.ctypes.data))
+    agg.close()

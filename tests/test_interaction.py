@@ -131,6 +131,102 @@ def test_oracle_interaction_transform_equals_reference_live():
     assert np.array_equal(ob.transform_interaction_batch(rec).view(np.uint32), ref)
 
 
+def check_instance_interactions(got, rows, kind, rays, hits, verts, normals, tri_vertices, patch_vertices, m, mi):
+    """Device records `got[rows]` of hits inside instances against the oracle composed of pinned pieces: the
+    shape's InteractionFromIntersection in the instance's space (wo = -ApplyInverse(ray.d)), then
+    Transform::operator()(SurfaceInteraction) with the per-row matrices m / mi ([n, 3, 4])."""
+    d = rays["d"][rows]
+    d_in = np.stack([(mi[:, i, 0] * d[:, 0] + mi[:, i, 1] * d[:, 1]) + mi[:, i, 2] * d[:, 2] for i in range(3)], 1)
+    if kind == 0:
+        rec = np.zeros((len(rows), 45), np.float32)
+        tv = tri_vertices[hits["prim"][rows]]
+        rec[:, 0:9] = verts[tv].reshape(-1, 9)
+        rec[:, 9], rec[:, 10], rec[:, 11] = hits["b0"][rows], hits["b1"][rows], hits["b2"][rows]
+        rec[:, 12:15] = -d_in
+        rec[:, 18] = rays["time"][rows]
+        rec[:, 19] = 2
+        rec[:, 26:35] = normals[tv].reshape(-1, 9)
+        local = ob.triangle_interaction_batch(rec)
+        gdn = np.zeros((len(rows), 6), np.float32)
+    else:
+        rec = np.zeros((len(rows), 40), np.float32)
+        pv = patch_vertices[hits["prim"][rows]]
+        rec[:, 0:12] = verts[pv].reshape(-1, 12)
+        rec[:, 12], rec[:, 13] = hits["b0"][rows], hits["b1"][rows]
+        rec[:, 14:17] = -d_in
+        rec[:, 17] = rays["time"][rows]
+        rec[:, 18] = 2
+        rec[:, 27:39] = normals[pv].reshape(-1, 12)
+        local = ob.patch_interaction_batch(rec)
+        gdn = local[:, 44:50]
+    xf = np.zeros((len(rows), 72), np.float32)
+    for half, mat in ((0, m), (16, mi)):
+        m44 = np.zeros((len(rows), 4, 4), np.float32)
+        m44[:, :3, :] = mat
+        m44[:, 3, 3] = 1
+        xf[:, half:half + 16] = m44.reshape(-1, 16)
+    xf[:, 32:38] = local[:, 38:44]                       # pi low / high
+    xf[:, 38:41], xf[:, 41:44] = local[:, 11:14], local[:, 8:11]   # n, wo
+    xf[:, 44:50] = local[:, 14:20]                       # dpdu dpdv
+    xf[:, 50:56] = gdn                                   # geometric dndu dndv
+    xf[:, 56:71] = local[:, 20:35]                       # shading n dpdu dpdv dndu dndv
+    exp = ob.transform_interaction_batch(xf)
+    g = got[rows]
+    for name, sl in (("pi_lo", slice(0, 3)), ("pi_hi", slice(3, 6)), ("n", slice(6, 9)), ("wo", slice(9, 12)),
+                     ("dpdu", slice(12, 15)), ("dpdv", slice(15, 18)), ("dndu", slice(18, 21)),
+                     ("dndv", slice(21, 24)), ("ns", slice(24, 27)), ("dpdus", slice(27, 30)),
+                     ("dpdvs", slice(30, 33)), ("dndus", slice(33, 36)), ("dndvs", slice(36, 39))):
+        a = np.ascontiguousarray(g[name]).view(np.uint32)
+        b = np.ascontiguousarray(exp[:, sl]).view(np.uint32)
+        bad = np.nonzero((a != b).any(1))[0]
+        assert len(bad) == 0, f"kind {kind}: {name} differs on {len(bad)} of {len(rows)} records"
+    # the (u, v) of the hit are not touched by the transform
+    assert np.array_equal(g["uv"].view(np.uint32), np.ascontiguousarray(local[:, 6:8]).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_interactions_inside_animated_instances():
+    """Hits inside AnimatedPrimitives (cpu/primitive.cpp:143-153): the interaction in the instance's space,
+    then Interpolate(ray.time) applied to it — on the device, against the oracle composed of
+    AnimatedTransform::Interpolate (pinned to the compiled reference; run with the device's sine, the
+    path's documented exception), the shape's InteractionFromIntersection and Transform(SurfaceInteraction)."""
+    import test_animated as ta
+    from nn_bvh_amd import BVHAggregate, scene
+    from nn_bvh_amd.interaction import ShadingMesh
+    verts, prims, _, _, _, _, anims, oa, placements = ta.animated_scene(4, 36)
+    nodes, aprims, instances, n_top = ta.rebuild_with_motion_bounds(verts, prims, placements, anims, oa)
+    aprims = aprims.copy()
+    obj = aprims["kind"] != 2  # the object's primitives; instance primitives keep their ids
+    n_ids = int(aprims["id"][obj].max()) + 1
+    tri_vertices = np.full((n_ids, 3), -1, np.int32)
+    tri_vertices[aprims["id"][obj]] = aprims["v"][obj][:, :3]
+    rng = np.random.default_rng(18)
+    normals = rng.normal(size=(len(verts), 3)).astype(np.float32)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    mesh = ShadingMesh(verts, tri_vertices, normals=normals)
+    agg = BVHAggregate.from_tree(nodes, aprims, verts, instances=instances, n_top_nodes=n_top, animated=anims)
+    rays = scene.random_rays(60000, [-25, -25, -25], [25, 25, 25], 5)
+    rays["time"] = np.random.default_rng(6).uniform(-0.2, 1.2, len(rays)).astype(np.float32)
+    hits = agg.Intersect(rays)
+    mesh.set_instances(instances, animated=anims)
+    got = mesh.interactions(rays, hits)
+    rows = np.nonzero((hits["prim"] >= 0) & (hits["instance"] > 0))[0]
+    assert len(rows) > 3000 and (got["status"][rows] == 1).all()
+    k = hits["instance"][rows] - 1
+    try:
+        ob.set_sin_mode(1)
+        mm = ob.anim_interpolate(oa[k], rays["time"][rows])   # [n, 32]: m, mInv (4 x 4 each)
+    finally:
+        ob.set_sin_mode(0)
+    m = mm[:, :16].reshape(-1, 4, 4)[:, :3, :]
+    mi = mm[:, 16:].reshape(-1, 4, 4)[:, :3, :]
+    moving = (anims["actually_animated"][k] != 0) & (rays["time"][rows] > 0) & (rays["time"][rows] < 1)
+    assert moving.sum() > 1000  # the interpolated transform is what most of these records went through
+    check_instance_interactions(got, rows, 0, rays, hits, verts, normals, tri_vertices, None, m, mi)
+    agg.close()
+    mesh.close()
+
+
 @pytest.mark.gpu
 def test_gpu_interactions_inside_instances():
     """Hits inside instances: interaction in the instance's space, then renderFromPrimitive applied
@@ -167,53 +263,8 @@ def test_gpu_interactions_inside_instances():
         assert len(rows) > (200 if kind == 0 else 20)
         assert (got["status"][rows] == status).all()
         inst = instances[hits["instance"][rows] - 1]
-        mi = inst["prim_from_render"].reshape(-1, 3, 4)
-        d = rays["d"][rows]
-        d_in = np.stack([(mi[:, i, 0] * d[:, 0] + mi[:, i, 1] * d[:, 1]) + mi[:, i, 2] * d[:, 2] for i in range(3)], 1)
-        if kind == 0:
-            rec = np.zeros((len(rows), 45), np.float32)
-            tv = tri_vertices[hits["prim"][rows]]
-            rec[:, 0:9] = verts[tv].reshape(-1, 9)
-            rec[:, 9], rec[:, 10], rec[:, 11] = hits["b0"][rows], hits["b1"][rows], hits["b2"][rows]
-            rec[:, 12:15] = -d_in
-            rec[:, 18] = rays["time"][rows]
-            rec[:, 19] = 2
-            rec[:, 26:35] = normals[tv].reshape(-1, 9)
-            local = ob.triangle_interaction_batch(rec)
-            gdn = np.zeros((len(rows), 6), np.float32)
-        else:
-            rec = np.zeros((len(rows), 40), np.float32)
-            pv = patch_vertices[hits["prim"][rows]]
-            rec[:, 0:12] = verts[pv].reshape(-1, 12)
-            rec[:, 12], rec[:, 13] = hits["b0"][rows], hits["b1"][rows]
-            rec[:, 14:17] = -d_in
-            rec[:, 17] = rays["time"][rows]
-            rec[:, 18] = 2
-            rec[:, 27:39] = normals[pv].reshape(-1, 12)
-            local = ob.patch_interaction_batch(rec)
-            gdn = local[:, 44:50]
-        xf = np.zeros((len(rows), 72), np.float32)
-        for half, name in ((0, "render_from_prim"), (16, "prim_from_render")):
-            m44 = np.zeros((len(rows), 4, 4), np.float32)
-            m44[:, :3, :] = inst[name].reshape(-1, 3, 4)
-            m44[:, 3, 3] = 1
-            xf[:, half:half + 16] = m44.reshape(-1, 16)
-        xf[:, 32:38] = local[:, 38:44]                       # pi low / high
-        xf[:, 38:41], xf[:, 41:44] = local[:, 11:14], local[:, 8:11]   # n, wo
-        xf[:, 44:50] = local[:, 14:20]                       # dpdu dpdv
-        xf[:, 50:56] = gdn                                   # geometric dndu dndv
-        xf[:, 56:71] = local[:, 20:35]                       # shading n dpdu dpdv dndu dndv
-        exp = ob.transform_interaction_batch(xf)
-        g = got[rows]
-        for name, sl in (("pi_lo", slice(0, 3)), ("pi_hi", slice(3, 6)), ("n", slice(6, 9)), ("wo", slice(9, 12)),
-                         ("dpdu", slice(12, 15)), ("dpdv", slice(15, 18)), ("dndu", slice(18, 21)),
-                         ("dndv", slice(21, 24)), ("ns", slice(24, 27)), ("dpdus", slice(27, 30)),
-                         ("dpdvs", slice(30, 33)), ("dndus", slice(33, 36)), ("dndvs", slice(36, 39))):
-            a = np.ascontiguousarray(g[name]).view(np.uint32)
-            b = np.ascontiguousarray(exp[:, sl]).view(np.uint32)
-            bad = np.nonzero((a != b).any(1))[0]
-            assert len(bad) == 0, f"kind {kind}: {name} differs on {len(bad)} of {len(rows)} records"
-        assert np.array_equal(g["uv"].view(np.uint32), np.ascontiguousarray(local[:, 6:8]).view(np.uint32))
+        check_instance_interactions(got, rows, kind, rays, hits, verts, normals, tri_vertices, patch_vertices,
+                                    inst["render_from_prim"].reshape(-1, 3, 4), inst["prim_from_render"].reshape(-1, 3, 4))
     agg.close()
     mesh.close()
 

@@ -138,7 +138,7 @@ def main():
         p0 = t(rng.uniform([-3.5, -3.5, -5], [3.5, 3.5, 5], (n, 3)).astype(np.float32))
         p1 = t(rng.uniform([-3.5, -3.5, -5], [3.5, 3.5, 5], (n, 3)).astype(np.float32))
         material = t(rng.integers(0, 3, n).astype(np.int32))
-        prim_mat = rng.integers(0, 3, len(tris)).astype(np.int32)
+        prim_mat = t(rng.integers(0, 3, len(tris)).astype(np.int32))
         timed(torch, "IntersectOneRandom", n, lambda: wf.IntersectOneRandom(n, p0, p1, material, mesh, prim_mat), reps=3)
     elif which == "intr":
         sys.argv = [sys.argv[0]]
