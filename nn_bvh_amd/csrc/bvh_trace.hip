@@ -36,6 +36,7 @@ namespace nnbvh {
 // ------------------------------------------------------------------------------------
 constexpr int kDone = (int)0x80000000;    // never a leaf ref: ~slot with slot = 0x7fffffff
 constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is exhausted (slot 0x7ffffffe)
+constexpr int kEnter = (int)0x80000002;   // INST = 2: the lane waits to enter an AnimatedPrimitive (slot 0x7ffffffd)
 
 // MODE 0: closest hit (counts always)
 // MODE 1: any hit with exact node-visit / prim-test counts (pushes every far child)
@@ -60,6 +61,16 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 #endif
 #ifndef NNBVH_MINW_ANY
 #define NNBVH_MINW_ANY 6
+#endif
+// the ALPHA instances (hash + re-trace in the primitive step): at 6 waves they spill 8-18 registers, at 5 none —
+// a 1 M-triangle soup with 70 % alpha-tested triangles: closest 6.26 -> 4.95 ms, any 5.38 -> 4.52 ms
+#ifndef NNBVH_MINW_ALPHA
+#define NNBVH_MINW_ALPHA 5
+#endif
+// INST = 2: weight of a lane waiting to enter an AnimatedPrimitive in the step selection (interior = 16); 0 = enter
+// at once inside the primitive step (the round-2 form: 11 of 64 lanes active in the interpolation)
+#ifndef NNBVH_ANIM_ENTER_WEIGHT
+#define NNBVH_ANIM_ENTER_WEIGHT 8
 #endif
 #ifndef NNBVH_FUSED_PRIM_LOOP
 #define NNBVH_FUSED_PRIM_LOOP 0
@@ -98,7 +109,7 @@ constexpr int kReturn = (int)0x80000001;  // an instance's child traversal is ex
 // ALPHA = 1: the scene holds alpha-tested triangles (kPrimAlpha, cpu/primitive.cpp:57-70); compiled
 // separately so that other scenes pay nothing for the hash and the re-trace.
 template <int MODE, int W, int INST, int PATCH, int ALPHA = 0>
-__global__ __launch_bounds__(kBlockThreads, (INST ? 1 : ((MODE == 0 || MODE == 3) ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY) + (PATCH ? 0 : NNBVH_LEAN_EXTRA_WAVES)))
+__global__ __launch_bounds__(kBlockThreads, (INST ? 1 : (ALPHA ? NNBVH_MINW_ALPHA : ((MODE == 0 || MODE == 3) ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY) + (PATCH ? 0 : NNBVH_LEAN_EXTRA_WAVES))))
 void trace_kernel(TraceParams p) {
     static_assert(PATCH || !INST, "two-level scenes need the ray direction");
     static_assert(PATCH || !ALPHA, "the alpha test hashes the ray direction");
@@ -121,8 +132,8 @@ void trace_kernel(TraceParams p) {
     constexpr int kSaveO = kColdBase, kSaveInv = kColdBase + 3, kSaveShear = kColdBase + 6,
                   kSaveKz = kColdBase + 9, kSaveTmax = kColdBase + 10, kSaveD = kColdBase + 11,
                   kResume = kColdBase + 14, kCurInst = kColdBase + 15, kHitInst = kColdBase + 16,
-                  kInnerHit = kColdBase + 17, kColdTime = kColdBase + 18;
-    constexpr int kColdFields = kColdBase + (INST ? 19 : 0);
+                  kInnerHit = kColdBase + 17, kColdTime = kColdBase + 18, kPendSlot = kColdBase + 19;
+    constexpr int kColdFields = kColdBase + (INST ? 20 : 0);
     __shared__ float s_cold[kBlockThreads / 64][kColdFields > 0 ? kColdFields : 1][64];
 
     const int lane = threadIdx.x & 63;
@@ -266,7 +277,14 @@ void trace_kernel(TraceParams p) {
     auto prim_math = [&](const int slot, const float4 s0, const float4 s1, const float4 s2) {
         const unsigned flags = __float_as_uint(s1.w);
         if (INST && (flags & kPrimInstance)) {
-            enter_instance(slot, flags, s0, s1, s2);
+            if (INST == 2 && NNBVH_ANIM_ENTER_WEIGHT > 0 && (flags & kPrimAnimated) && p.anim) {
+                // Interpolate(ray.time) costs ~600 instructions: the lane waits in the kEnter state until the
+                // wave runs an ENTER step for all lanes that have reached an AnimatedPrimitive by then
+                cold[kPendSlot][lane] = __int_as_float(slot);
+                cur = kEnter;
+            } else {
+                enter_instance(slot, flags, s0, s1, s2);
+            }
         } else if (!kLean && (flags & kPrimHost)) {
             // a primitive only the host can intersect (quadric, curve, alpha-tested
             // ...): this ray's result is void and the caller re-traces it on the CPU
@@ -423,7 +441,8 @@ void trace_kernel(TraceParams p) {
         const int nInt = __popcll(__ballot(isInt));
         const unsigned long long idleMask = __ballot(isIdle);
         const int nIdle = __popcll(idleMask);
-        const int nPrim = 64 - nInt - nIdle;
+        const int nEnter = (INST == 2 && NNBVH_ANIM_ENTER_WEIGHT > 0) ? __popcll(__ballot(cur == kEnter)) : 0;
+        const int nPrim = 64 - nInt - nIdle - nEnter;
 
         // Wave-uniform choice of this trip's step kind: the one that advances the most lanes
         // per instruction issued.  A lane's weight says how cheap its step is relative to an
@@ -575,6 +594,17 @@ void trace_kernel(TraceParams p) {
             continue;
         }
 
+        if (INST == 2 && NNBVH_ANIM_ENTER_WEIGHT > 0 && nEnter > 0 &&
+            ((nInt == 0 && nPrim == 0) || (nEnter * NNBVH_ANIM_ENTER_WEIGHT > sI && nEnter * NNBVH_ANIM_ENTER_WEIGHT > sP))) {
+            // ---- enter step: every lane waiting at an AnimatedPrimitive enters it now -------------------
+            if (cur == kEnter) {
+                const int slot = __float_as_int(cold[kPendSlot][lane]);
+                const float4 s0 = p.prims[slot], s1 = p.prims[slot + 1], s2 = p.prims[slot + 2];
+                enter_instance(slot, __float_as_uint(s1.w), s0, s1, s2);
+            }
+            continue;
+        }
+
         if (kLean && NNBVH_MERGED && p.primMin > 0) {
             // ---- merged trip (lean instances): every lane with a node pending, and — when at least
             // p.primMin lanes wait on a leaf, or nobody has a node — every lane with a primitive pending,
@@ -615,7 +645,7 @@ void trace_kernel(TraceParams p) {
             do {
             if (cur < 0 && cur != kDone) {
                 if (INST && cur == kReturn) leave_instance();
-                if (cur < 0 && cur != kDone && cur != kReturn) {
+                if (cur < 0 && cur != kDone && cur != kReturn && (INST != 2 || cur != kEnter)) {
                     const int slot = ~cur;
                     const float4 *pr = kLean ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.prims) + ((unsigned)slot << 4))
                                              : p.prims + slot;

@@ -7,6 +7,7 @@ tools/profile_bench.sh --script tools/profile_workloads.py <which> for rocprofv3
     anim      36 placements of a small mesh, 24 of them AnimatedPrimitives (tests/test_animated.py's scene): INST = 2
     tr        IntersectShadowTr and IntersectOneRandom over 2 M items on sheets of interface surfaces: str_* / or_*
     intr      k_triangle_interactions on 11.2 M crown primary hit records
+    crown_primary | crown_bounce | crown_bounce2 | crown_shadow   one ray class of the bench step alone
 Prints one line per timed call."""
 import os
 import sys
@@ -140,6 +141,30 @@ def main():
         material = t(rng.integers(0, 3, n).astype(np.int32))
         prim_mat = t(rng.integers(0, 3, len(tris)).astype(np.int32))
         timed(torch, "IntersectOneRandom", n, lambda: wf.IntersectOneRandom(n, p0, p1, material, mesh, prim_mat), reps=3)
+    elif which.startswith("crown_"):
+        # one ray class of the crown step alone, as ONE-batch launches of the one-launch kernel (trace_kernel<3>): the
+        # batches are generated with the separate-launch kernels (<0>), so the <3> rows of a profile are this class only
+        cls = which[len("crown_"):]
+        verts, tris, source = scene.load_scene("crown")
+        tree = build_tree(make_prims(tris), verts)
+        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+        _, px, py = scene.camera_rays("crown", seed=1, sample=0, return_pixels=True)
+        tiles = np.lexsort((px, py, px // 4, py // 4))
+        primary = np.stack([scene.camera_rays("crown", seed=1, sample=s) for s in range(8)], 1)[tiles].reshape(-1)
+        hits = agg.Intersect(primary)
+        rays, kind = primary, "closest"
+        if cls in ("bounce", "bounce2"):
+            rays = scene.bounce_rays(primary, hits, verts, tris, seed=2)
+            if cls == "bounce2":
+                rays = scene.bounce_rays(rays, agg.Intersect(rays), verts, tris, seed=4)
+        elif cls == "shadow":
+            rays, kind = scene.shadow_rays_to_quads(primary, hits, verts, tris, scene.CROWN_LIGHT_QUADS, seed=3), "any"
+        n = len(rays)
+        d_r = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+        d_o = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        timed(torch, f"crown {cls} ({kind}), one-batch launches of trace_kernel<3>", n,
+              lambda: agg.trace_batches_device([(kind, d_r.data_ptr(), n, d_o.data_ptr())], st), reps=6)
     elif which == "intr":
         sys.argv = [sys.argv[0]]
         import interaction_probe
