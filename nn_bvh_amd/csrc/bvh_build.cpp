@@ -262,35 +262,12 @@ inline uint32_t encode_morton3(float x, float y, float z) {  // util/math.h:114-
            left_shift3((uint32_t)x);
 }
 
-void radix_sort(std::vector<MortonPrim> *v) {  // aggregates.cpp:41-82
-    std::vector<MortonPrim> temp(v->size());
-    constexpr int bitsPerPass = 6, nBits = 30, nPasses = nBits / bitsPerPass;
-    for (int pass = 0; pass < nPasses; ++pass) {
-        int lowBit = pass * bitsPerPass;
-        std::vector<MortonPrim> &in = (pass & 1) ? temp : *v;
-        std::vector<MortonPrim> &out = (pass & 1) ? *v : temp;
-        constexpr int nBuckets = 1 << bitsPerPass, bitMask = nBuckets - 1;
-        int count[nBuckets] = {0};
-        for (const MortonPrim &mp : in) ++count[(mp.code >> lowBit) & bitMask];
-        int outIndex[nBuckets];
-        outIndex[0] = 0;
-        for (int i = 1; i < nBuckets; ++i) outIndex[i] = outIndex[i - 1] + count[i - 1];
-        for (const MortonPrim &mp : in) out[outIndex[(mp.code >> lowBit) & bitMask]++] = mp;
-    }
-    if (nPasses & 1) std::swap(*v, temp);
-}
-
-template <typename Pred>
-size_t find_interval(size_t sz, const Pred &pred) {  // util/math.h:508-520
-    long size = (long)sz - 2, first = 1;
-    while (size > 0) {
-        size_t half = (size_t)size >> 1, middle = first + half;
-        bool r = pred(middle);
-        first = r ? (long)middle + 1 : first;
-        size = r ? size - (long)(half + 1) : (long)half;
-    }
-    long lo = first - 1, hi = (long)sz - 2;
-    return (size_t)(lo < 0 ? 0 : (lo > hi ? hi : lo));
+// The reference orders the primitives with an LSD radix sort over the 30 code bits (aggregates.cpp:41-82): a
+// stable sort by the code, which is all the result depends on
+void sort_by_code(std::vector<MortonPrim> *v) {
+    std::stable_sort(v->begin(), v->end(), [](const MortonPrim &a, const MortonPrim &b) {
+        return (a.code & 0x3fffffffu) < (b.code & 0x3fffffffu);
+    });
 }
 
 struct HLBuilder {
@@ -315,10 +292,10 @@ struct HLBuilder {
         }
         uint32_t mask = 1u << bitIndex;
         if ((mp[0].code & mask) == (mp[n - 1].code & mask)) return emit(mp, n, bitIndex - 1);
-        int split = (int)find_interval((size_t)n, [&](size_t i) {
-            return (mp[0].code & mask) == (mp[i].code & mask);
-        });
-        ++split;
+        // the codes are sorted and agree above this bit, so the bit reads 0...0 1...1 over the range and the first
+        // primitive differs from the last: the split is where it flips (the reference's FindInterval + 1, :478-482)
+        const uint32_t firstBit = mp[0].code & mask;
+        const int split = (int)(std::partition_point(mp, mp + n, [&](const MortonPrim &q) { return (q.code & mask) == firstBit; }) - mp);
         BuildNode *node = b.alloc();
         node->child[0] = emit(mp, split, bitIndex - 1);
         node->child[1] = emit(mp + split, n - split, bitIndex - 1);
@@ -416,7 +393,7 @@ struct HLBuilder {
             mp[i].code = encode_morton3(cb.offset(c, 0) * mortonScale, cb.offset(c, 1) * mortonScale,
                                         cb.offset(c, 2) * mortonScale);
         }
-        radix_sort(&mp);
+        sort_by_code(&mp);
         std::vector<BuildNode *> roots;
         for (size_t start = 0, end = 1; end <= mp.size(); ++end) {
             const uint32_t mask = 0b00111111111111000000000000000000u;

@@ -1,16 +1,19 @@
-// kd_build.cpp — host-side construction of pbrt's KdTreeAggregate (no GPU needed).
+// kd_build.cpp — host-side construction of pbrt's KdTreeAggregate, and the C ABI of all three builders.
 //
-// Restates /root/reference/src/pbrt/cpu/aggregates.cpp:798-971 on flat arrays:
-//   KdTreeAggregate ctor   :798-835   maxDepth = round(8 + 1.3 log2 n), primitive bounds, work arrays
+// What is computed is /root/reference/src/pbrt/cpu/aggregates.cpp:798-971:
+//   KdTreeAggregate ctor   :798-835   maxDepth = round(8 + 1.3 log2 n), primitive bounds
 //   KdTreeNode::InitLeaf   :837-850   flags = 3 | n << 2; one index in the node, more in primitiveIndices
-//   buildTree              :852-971   per node: edges of the longest axis sorted by (t, type), SAH cost of
-//                                     every edge inside the node with the empty bonus, up to two retries
-//                                     on the other axes, bad-refine counting, prims below / above
-// The element order std::sort leaves among equal (t, type) keys decides ties between equal-cost
-// splits and the order of primitives in the leaves; the reference gets it from libstdc++'s
-// std::sort, and so does this file (same comparator, same element type, same input order).
-// Parity: "unpinned" — KdTreeAggregate cannot be built from the reference here (cpu/primitive.cpp
-// needs the absent nanovdb header), and the reference holds no fixture for it.
+//   buildTree              :852-971   per node: the bound edges of the longest axis sorted by (t, type), the SAH
+//                                     cost of every edge inside the node with the empty bonus, up to two retries
+//                                     on the other axes, bad-refine counting, primitives below / above
+// written as three small pieces (choose_split, make_leaf, grow) over per-node primitive lists.
+// The order a sort leaves among EQUAL (t, type) edges only decides the order of primitives inside
+// multi-primitive leaves (kd_build_gpu.hip explains why, tests/test_kd_build_gpu.py checks it):
+//   nnbvh_kd_build_create          std::sort — libstdc++'s order, what a libstdc++ build of pbrt produces
+//   nnbvh_kd_build_create_stable   std::stable_sort — list order: the device builder's byte-for-byte checker
+//   nnbvh_kd_build_create_gpu      the device builder (kd_build_gpu.hip)
+// Parity: "unpinned" — KdTreeAggregate cannot be built from the reference here (cpu/primitive.cpp needs the
+// absent nanovdb header), and the reference holds no fixture for it.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -63,117 +66,108 @@ KBox box_union(const KBox &a, const KBox &b) {  // :1487-1492
     return r;
 }
 
-enum class EdgeType { Start, End };  // aggregates.cpp:778
-struct BoundEdge {                   // :781-794
+// ---- the builder --------------------------------------------------------------------------------------
+// One node = (its primitives in list order, its box, the depth it may still use, its bad-refine count).
+// choose_split() is the reference's sweep over the sorted bound edges of one axis (:896-935), emit() the
+// leaf / interior bookkeeping, and grow() the recursion — below child first, so that the node array comes out
+// in the reference's depth-first order with the above child's index known once the below sub-tree is complete.
+struct Edge {  // BoundEdge, :781-794
     float t;
-    int primNum;
-    EdgeType type;
+    int prim;
+    bool closes;  // EdgeType::End
+};
+// std::tie(t, type) < std::tie(t', type') with Start < End
+inline bool edge_before(const Edge &a, const Edge &b) { return a.t < b.t || (!(b.t < a.t) && !a.closes && b.closes); }
+
+struct Split {
+    int axis = -1, at = -1;  // position of the chosen edge in the sorted list
+    float cost = std::numeric_limits<float>::infinity();
 };
 
 struct KdBuilder {
     int isectCost, traversalCost, maxPrims;
     float emptyBonus;
     bool stableTies = false;  // equal (t, type) edges keep list order (std::stable_sort) instead of libstdc++'s std::sort order
+    const std::vector<KBox> *primBox = nullptr;
     std::vector<nnbvh_kd_node> nodes;
     std::vector<int32_t> primitiveIndices;
+    std::vector<Edge> edges;  // the 2n edges of the node being split, sorted
     int maxDepthReached = 0;
 
-    void init_leaf(int nodeNum, const int *primNums, size_t n) {  // :837-850
-        nnbvh_kd_node &nd = nodes[(size_t)nodeNum];
+    void make_leaf(int node, const std::vector<int> &prims) {  // KdTreeNode::InitLeaf, :837-850
+        nnbvh_kd_node &nd = nodes[(size_t)node];
+        const size_t n = prims.size();
         nd.flags = 3u | (uint32_t)(n << 2);
-        int32_t v;
-        if (n == 0)
-            v = 0;
-        else if (n == 1)
-            v = primNums[0];
-        else {
+        int32_t v = 0;
+        if (n == 1) v = prims[0];
+        else if (n > 1) {
             v = (int32_t)primitiveIndices.size();
-            for (size_t i = 0; i < n; ++i) primitiveIndices.push_back(primNums[i]);
+            primitiveIndices.insert(primitiveIndices.end(), prims.begin(), prims.end());
         }
         std::memcpy(&nd.split_or_index, &v, 4);
     }
 
-    void build(int nodeNum, const KBox &nodeBounds, const std::vector<KBox> &allPrimBounds, const int *primNums,
-               size_t nPrimNums, int depth, int level, std::vector<BoundEdge> edges[3], int *prims0, int *prims1,
-               int badRefines) {
-        // :860-871 the node array grows by doubling in the reference; a vector does the same job
-        if ((size_t)nodeNum != nodes.size()) std::abort();
+    void sort_edges(const std::vector<int> &prims, int axis) {
+        edges.resize(2 * prims.size());
+        for (size_t i = 0; i < prims.size(); ++i) {
+            const KBox &b = (*primBox)[(size_t)prims[i]];
+            edges[2 * i] = Edge{b.mn[axis], prims[i], false};
+            edges[2 * i + 1] = Edge{b.mx[axis], prims[i], true};
+        }
+        if (stableTies) std::stable_sort(edges.begin(), edges.end(), edge_before);
+        else std::sort(edges.begin(), edges.end(), edge_before);
+    }
+
+    // the cheapest edge strictly inside the box on `axis`, first minimum wins; leaves `edges` sorted on that axis
+    void choose_split(const std::vector<int> &prims, const KBox &box, int axis, Split *best) {
+        sort_edges(prims, axis);
+        const float d[3] = {box.mx[0] - box.mn[0], box.mx[1] - box.mn[1], box.mx[2] - box.mn[2]};
+        const float invTotalSA = 1 / (2 * (d[0] * d[1] + d[0] * d[2] + d[1] * d[2]));  // 1 / SurfaceArea, vecmath.h:1294-1297
+        const int u = (axis + 1) % 3, v = (axis + 2) % 3;
+        int below = 0, above = (int)prims.size();
+        for (size_t i = 0; i < edges.size(); ++i) {
+            const Edge &e = edges[i];
+            if (e.closes) --above;
+            if (e.t > box.mn[axis] && e.t < box.mx[axis]) {
+                const float belowSA = 2 * (d[u] * d[v] + (e.t - box.mn[axis]) * (d[u] + d[v]));
+                const float aboveSA = 2 * (d[u] * d[v] + (box.mx[axis] - e.t) * (d[u] + d[v]));
+                const float pBelow = belowSA * invTotalSA, pAbove = aboveSA * invTotalSA;
+                const float eb = (above == 0 || below == 0) ? emptyBonus : 0;
+                const float cost = traversalCost + isectCost * (1 - eb) * (pBelow * below + pAbove * above);
+                if (cost < best->cost) *best = Split{axis, (int)i, cost};
+            }
+            if (!e.closes) ++below;
+        }
+    }
+
+    void grow(std::vector<int> prims, const KBox &box, int depthLeft, int level, int badRefines) {
+        const int node = (int)nodes.size();
         nodes.emplace_back();
-        if (level > maxDepthReached) maxDepthReached = level;
-        if ((int)nPrimNums <= maxPrims || depth == 0) {  // :874-877
-            init_leaf(nodeNum, primNums, nPrimNums);
-            return;
-        }
-        int bestAxis = -1, bestOffset = -1;
-        float bestCost = std::numeric_limits<float>::infinity();
-        const float leafCost = (float)((size_t)isectCost * nPrimNums);
-        const float dx = nodeBounds.mx[0] - nodeBounds.mn[0], dy = nodeBounds.mx[1] - nodeBounds.mn[1],
-                    dz = nodeBounds.mx[2] - nodeBounds.mn[2];
-        const float invTotalSA = 1 / (2 * (dx * dy + dx * dz + dy * dz));  // SurfaceArea, vecmath.h:1294-1297
-        int axis = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);           // MaxDimension, :1306-1314
-        int retries = 0;
-        const size_t nPrimitives = nPrimNums;
-        for (;;) {  // retrySplit
-            for (size_t i = 0; i < nPrimitives; ++i) {
-                const int pn = primNums[i];
-                const KBox &b = allPrimBounds[(size_t)pn];
-                edges[axis][2 * i] = BoundEdge{b.mn[axis], pn, EdgeType::Start};
-                edges[axis][2 * i + 1] = BoundEdge{b.mx[axis], pn, EdgeType::End};
-            }
-            const auto less = [](const BoundEdge &e0, const BoundEdge &e1) -> bool {
-                return std::tie(e0.t, e0.type) < std::tie(e1.t, e1.type);
-            };
-            if (stableTies) std::stable_sort(edges[axis].begin(), edges[axis].begin() + 2 * nPrimitives, less);
-            else std::sort(edges[axis].begin(), edges[axis].begin() + 2 * nPrimitives, less);
-            int nBelow = 0, nAbove = (int)nPrimNums;
-            for (size_t i = 0; i < 2 * nPrimNums; ++i) {
-                if (edges[axis][i].type == EdgeType::End) --nAbove;
-                const float edgeT = edges[axis][i].t;
-                if (edgeT > nodeBounds.mn[axis] && edgeT < nodeBounds.mx[axis]) {
-                    const float d[3] = {dx, dy, dz};
-                    const int otherAxis0 = (axis + 1) % 3, otherAxis1 = (axis + 2) % 3;
-                    const float belowSA = 2 * (d[otherAxis0] * d[otherAxis1] +
-                                               (edgeT - nodeBounds.mn[axis]) * (d[otherAxis0] + d[otherAxis1]));
-                    const float aboveSA = 2 * (d[otherAxis0] * d[otherAxis1] +
-                                               (nodeBounds.mx[axis] - edgeT) * (d[otherAxis0] + d[otherAxis1]));
-                    const float pBelow = belowSA * invTotalSA, pAbove = aboveSA * invTotalSA;
-                    const float eb = (nAbove == 0 || nBelow == 0) ? emptyBonus : 0;
-                    const float cost = traversalCost + isectCost * (1 - eb) * (pBelow * nBelow + pAbove * nAbove);
-                    if (cost < bestCost) {
-                        bestCost = cost;
-                        bestAxis = axis;
-                        bestOffset = (int)i;
-                    }
-                }
-                if (edges[axis][i].type == EdgeType::Start) ++nBelow;
-            }
-            if (bestAxis == -1 && retries < 2) {  // :938-942
-                ++retries;
-                axis = (axis + 1) % 3;
-                continue;
-            }
-            break;
-        }
-        if (bestCost > leafCost) ++badRefines;  // :945-951
-        if ((bestCost > 4 * leafCost && nPrimitives < 16) || bestAxis == -1 || badRefines == 3) {
-            init_leaf(nodeNum, primNums, nPrimNums);
-            return;
-        }
-        int n0 = 0, n1 = 0;  // :954-960
-        for (int i = 0; i < bestOffset; ++i)
-            if (edges[bestAxis][(size_t)i].type == EdgeType::Start) prims0[n0++] = edges[bestAxis][(size_t)i].primNum;
-        for (size_t i = (size_t)bestOffset + 1; i < 2 * nPrimitives; ++i)
-            if (edges[bestAxis][i].type == EdgeType::End) prims1[n1++] = edges[bestAxis][i].primNum;
-        const float tSplit = edges[bestAxis][(size_t)bestOffset].t;  // :963-970
-        KBox bounds0 = nodeBounds, bounds1 = nodeBounds;
-        bounds0.mx[bestAxis] = bounds1.mn[bestAxis] = tSplit;
-        build(nodeNum + 1, bounds0, allPrimBounds, prims0, (size_t)n0, depth - 1, level + 1, edges, prims0,
-              prims1 + n1, badRefines);
+        maxDepthReached = std::max(maxDepthReached, level);
+        if ((int)prims.size() <= maxPrims || depthLeft == 0) return make_leaf(node, prims);  // :874-877
+        // longest axis first, then the other two if no edge lies inside the box (:882-942)
+        const float dx = box.mx[0] - box.mn[0], dy = box.mx[1] - box.mn[1], dz = box.mx[2] - box.mn[2];
+        int axis = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);  // MaxDimension, vecmath.h:1306-1314
+        Split best;
+        for (int attempt = 0; attempt < 3 && best.axis < 0; ++attempt, axis = (axis + 1) % 3) choose_split(prims, box, axis, &best);
+        const float leafCost = (float)((size_t)isectCost * prims.size());
+        if (best.cost > leafCost) ++badRefines;  // :945-951
+        if ((best.cost > 4 * leafCost && prims.size() < 16) || best.axis < 0 || badRefines == 3) return make_leaf(node, prims);
+        // primitives that open before the chosen edge go below, those that close after it above (:954-960)
+        std::vector<int> lower, upper;
+        for (int i = 0; i < best.at; ++i)
+            if (!edges[(size_t)i].closes) lower.push_back(edges[(size_t)i].prim);
+        for (size_t i = (size_t)best.at + 1; i < edges.size(); ++i)
+            if (edges[i].closes) upper.push_back(edges[i].prim);
+        const float tSplit = edges[(size_t)best.at].t;
+        prims = std::vector<int>();  // the parent's list is not needed below here
+        KBox lowerBox = box, upperBox = box;
+        lowerBox.mx[best.axis] = upperBox.mn[best.axis] = tSplit;
+        grow(std::move(lower), lowerBox, depthLeft - 1, level + 1, badRefines);
         const int aboveChild = (int)nodes.size();
-        nodes[(size_t)nodeNum].flags = (uint32_t)bestAxis | ((uint32_t)aboveChild << 2);  // InitInterior, :756-759
-        std::memcpy(&nodes[(size_t)nodeNum].split_or_index, &tSplit, 4);
-        build(aboveChild, bounds1, allPrimBounds, prims1, (size_t)n1, depth - 1, level + 1, edges, prims0,
-              prims1 + n1, badRefines);
+        nodes[(size_t)node].flags = (uint32_t)best.axis | ((uint32_t)aboveChild << 2);  // InitInterior, :756-759
+        std::memcpy(&nodes[(size_t)node].split_or_index, &tSplit, 4);
+        grow(std::move(upper), upperBox, depthLeft - 1, level + 1, badRefines);
     }
 };
 
@@ -257,13 +251,10 @@ static nnbvh_kd_build *kd_build_host(const nnbvh_prim *prims, int n_prims, const
     kb.emptyBonus = empty_bonus;
     kb.maxPrims = max_prims;
     kb.stableTies = stable_ties;
-    std::vector<BoundEdge> edges[3];
-    for (int i = 0; i < 3; ++i) edges[i].resize(2 * (size_t)n_prims);
-    std::vector<int> prims0((size_t)n_prims), prims1(((size_t)max_depth + 1) * (size_t)n_prims);
-    std::vector<int> primNums((size_t)n_prims);
-    for (int i = 0; i < n_prims; ++i) primNums[(size_t)i] = i;
-    kb.build(0, bounds, primBounds, primNums.data(), (size_t)n_prims, max_depth, 0, edges, prims0.data(),
-             prims1.data(), 0);
+    kb.primBox = &primBounds;
+    std::vector<int> all((size_t)n_prims);
+    for (int i = 0; i < n_prims; ++i) all[(size_t)i] = i;
+    kb.grow(std::move(all), bounds, max_depth, 0, 0);
     auto *out = new nnbvh_kd_build;
     out->nodes.swap(kb.nodes);
     out->prim_indices.swap(kb.primitiveIndices);
