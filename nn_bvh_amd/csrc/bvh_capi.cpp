@@ -994,7 +994,7 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
         p.fits32 = scene_fits32(s);
         p.primsOff = (unsigned)((const char *)s->d_prims - (const char *)s->d_wide);
         p.primMin = scene_prim_min(s);
-        p.hasHostPrims = s->has_host_prims;
+            p.hasHostPrims = s->has_host_prims;
         p.spill = w->spill;
         p.anim = s->d_anim;
         int64_t total = 0;

@@ -46,9 +46,16 @@ def draw_scene(rng):
         tri = prims["kind"] == 0
         kinds = rng.choice(np.array([0, 4, 5], np.int32), len(prims), p=[0.4, 0.3, 0.3])
         alpha = rng.choice(np.array([0.0, 0.25, 0.5, 0.9, 1.0, 1.5, -0.5], np.float32), len(prims))
+        # half of the alpha scenes: some of the meshes are smooth-shaded (kinds 6 / 7, vertex normals in the scene)
+        normals = None
+        if rng.random() < 0.5:
+            kinds = np.where((kinds != 0) & (rng.random(len(prims)) < 0.6), kinds + 2, kinds)
+            normals = rng.normal(size=(len(verts), 3)).astype(np.float32)
+            normals[rng.random(len(verts)) < 0.05] = 0  # ns falls back to the geometric normal
         prims["kind"] = np.where(tri, kinds, prims["kind"])
         prims["v"][:, 3] = np.where(tri & (kinds != 0), alpha.view(np.int32), prims["v"][:, 3])
-    return verts, prims
+        return verts, prims, normals
+    return verts, prims, None
 
 
 def draw_rays(rng, verts, prims, n):
@@ -192,16 +199,17 @@ def main():
     for it in range(args.iterations):
         seed = args.seed * 100003 + it
         rng = np.random.default_rng(seed)
-        verts, prims = draw_scene(rng)
+        verts, prims, normals = draw_scene(rng)
         split = str(rng.choice(["sah", "hlbvh", "middle", "equal"]))
         max_prims = int(rng.choice([1, 2, 4, 8]))
         tree = build_tree(prims, verts, max_prims, split)
-        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals)
+        ob.set_vertex_normals(normals)
         if rng.random() < 0.3:
             agg.set_option("stack_window", int(rng.choice([4, 16])))
         rays = draw_rays(rng, verts, prims, args.rays)
         bad, exp = compare(agg, tree, verts, rays)
-        if args.kd:
+        if args.kd and normals is None:  # (inside a kd-tree the smooth kinds are host-only primitives)
             kbad = compare_kd(verts, prims, rays, max_prims=int(rng.choice([1, 4])))
             if kbad:
                 print(f"KD MISMATCH seed {seed}: {len(kbad)} rays, first {kbad[:5]}", flush=True)

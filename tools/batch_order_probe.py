@@ -50,15 +50,19 @@ def main():
     for o in orders:
         t = float(np.median(times[o]))
         print(f"{' '.join(o):14s} {t:7.3f} ms  {n / t / 1e3:7.1f} Mray/s", flush=True)
-    if "--knobs" in sys.argv:  # scheduling knobs on the bench's order (S B2 B1 P), interleaved
+    if "--knobs" in sys.argv:  # scheduling knobs on the bench's order (S B2 B1 P), interleaved: --knobs a=1,2:b=3,4
         import itertools
+        spec = sys.argv[sys.argv.index("--knobs") + 1] if len(sys.argv) > sys.argv.index("--knobs") + 1 else \
+            "int_repeat=2,3,4:prim_weight=24,32,48:refill_weight=6,8,12"
+        keys = [kv.split("=")[0] for kv in spec.split(":")]
+        vals = [[int(x) for x in kv.split("=")[1].split(",")] for kv in spec.split(":")]
         o = ("S", "B2", "B1", "P")
         batches = [(B[k][0], B[k][1].data_ptr(), B[k][2], B[k][3].data_ptr()) for k in o]
-        combos = list(itertools.product((2, 3, 4), (24, 32, 48), (6, 8, 12)))
+        combos = list(itertools.product(*vals))
         kt = {c: [] for c in combos}
-        for rnd in range(5):
+        for rnd in range(6):
             for c in combos:
-                for key, v in zip(("int_repeat", "prim_weight", "refill_weight"), c):
+                for key, v in zip(keys, c):
                     agg.set_option(key, v)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
@@ -67,9 +71,9 @@ def main():
                 torch.cuda.synchronize()
                 if rnd:
                     kt[c].append(a.elapsed_time(b))
-        print("int_repeat prim_weight refill_weight | ms")
+        print(" ".join(keys), "| ms")
         for c in sorted(combos, key=lambda c: np.median(kt[c])):
-            print(f"{c[0]:10d} {c[1]:11d} {c[2]:13d} | {np.median(kt[c]):7.3f}", flush=True)
+            print(" ".join(f"{v:6d}" for v in c), f"| {np.median(kt[c]):7.3f}", flush=True)
 
 
 if __name__ == "__main__":
