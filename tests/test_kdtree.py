@@ -275,26 +275,28 @@ def test_device_kd_traversal_on_a_scene_blob_and_an_nss_style_tree():
 
 
 @pytest.mark.gpu
-def test_device_kd_traversal_on_bathroom_sampled_per_ray_class():
-    """bathroom's kd-tree (KdTreeAggregate::Create's defaults; V = 57.5, T = 34 per primary ray): a 60 k-ray
-    sample of each ray class — primary, diffuse bounce, shadow — against the oracle, as the BVH blob test does."""
+@pytest.mark.parametrize("name", ["bathroom", "crown"])
+def test_device_kd_traversal_on_scene_blobs_sampled_per_ray_class(name):
+    """bathroom's and crown's kd-trees (KdTreeAggregate::Create's defaults, built on the device; bathroom V = 57.5,
+    T = 34 per primary ray): a 60 k-ray sample of each ray class — primary, diffuse bounce, shadow — against the
+    oracle, as the BVH blob test does."""
     import os
-    if not os.path.exists(scene.blob_path("bathroom")):
-        pytest.skip("data/bathroom.npz not present")
-    verts, tris = scene.load_blob("bathroom")
+    if not os.path.exists(scene.blob_path(name)):
+        pytest.skip(f"data/{name}.npz not present")
+    verts, tris = scene.load_blob(name)
     prims = ss.make_prims(tris)
-    tree = build_kd_tree(prims, verts)
+    tree = build_kd_tree(prims, verts, where="gpu")
     agg = KdTreeAggregate.from_tree(tree.nodes, tree.prim_indices, prims, verts, tree.bounds)
-    primary = scene.camera_rays("bathroom", seed=1, sample=0)
+    primary = scene.camera_rays(name, seed=1, sample=0)
     hits = agg.Intersect(primary)
     idx = np.random.default_rng(1).choice(len(primary), 60000, replace=False)
     exp = ob.kd_closest(tree.nodes, tree.prim_indices, prims, verts, tree.bounds, primary[idx], 16)
-    assert hits[idx].tobytes() == exp.tobytes(), "bathroom kd primary"
+    assert hits[idx].tobytes() == exp.tobytes(), f"{name} kd primary"
     bounce = scene.bounce_rays(primary, hits, verts, tris)
     bh = agg.Intersect(bounce)
     idx = np.random.default_rng(2).choice(len(bounce), 60000, replace=False)
     assert bh[idx].tobytes() == ob.kd_closest(tree.nodes, tree.prim_indices, prims, verts, tree.bounds, bounce[idx],
-                                              16).tobytes(), "bathroom kd bounce"
+                                              16).tobytes(), f"{name} kd bounce"
     lo, hi = verts.min(0), verts.max(0)
     shadow = scene.shadow_rays(primary, hits, verts, tris, lo + (hi - lo) * [0.3, 0.9, 0.3],
                                lo + (hi - lo) * [0.7, 1.0, 0.7])
@@ -303,5 +305,5 @@ def test_device_kd_traversal_on_bathroom_sampled_per_ray_class():
     eo, ev, et = ob.kd_any_hit(tree.nodes, tree.prim_indices, prims, verts, tree.bounds, shadow[idx], 16)
     assert np.array_equal(occ[idx], eo) and np.array_equal(vis[idx], ev) and np.array_equal(tst[idx], et)
     assert np.array_equal(agg.IntersectP(shadow), occ)  # counting == non-counting, whole batch
-    assert (hits["prim"] >= 0).mean() > 0.9 and hits["nodes_visited"].mean() > 30
+    assert (hits["prim"] >= 0).mean() > (0.9 if name == "bathroom" else 0.7) and hits["nodes_visited"].mean() > 30
     agg.close()
