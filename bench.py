@@ -10,6 +10,7 @@ HBM, one launch per ray class:
     any-hit      over the shadow rays of the primary hits  (BVHAggregate::IntersectP, tMax = 1-1e-4)
     RecordShadowRayResult -> L per pixel sample, UpdateFilm / RGBFilm::AddSample -> the film's
     4 doubles per pixel (film.h:239-255, 302-307)
+The ray batches are synthetic, seeded and generated on the device before the timed region (nn_bvh_amd/raygen.py).
 value = rays traced by all ranks / wall time of K steps (max over ranks).  Consecutive steps
 trace different samples: --sample-sets (default 4) distinct sets of spp samples are resident and
 used round-robin.  BASELINE's "1024 spp" is extrapolated from these passes as SURVEY.md §8d
@@ -284,56 +285,66 @@ def main():
 
     lo, hi = verts.min(0), verts.max(0)
     t_gen = time.time()
+    # the batches are generated on the device (nn_bvh_amd/raygen.py: scene.py's recipes as vectorised passes over
+    # device arrays), so a rank does not spend tens of seconds of host time before its first step
+    from nn_bvh_amd import raygen
+    ds = raygen.DeviceScene(verts, tris, cdev)
+    d_pxm = torch.from_numpy(px[mine].astype(np.float64)).to(cdev)
+    d_pym = torch.from_numpy(py[mine].astype(np.float64)).to(cdev)
     sets = []
     for k in range(max(1, args.sample_sets)):
-        per_pass = [scene.camera_rays(cam_name, seed=1, sample=k * passes + s_idx, subset=mine)
-                    for s_idx in range(passes)]
+        per_pass = [ds.camera_rays(cam_name, d_pxm, d_pym, seed=1, sample=k * passes + s_idx) for s_idx in range(passes)]
         if args.ray_order != "sample":  # ray r = sample r % passes of slot r // passes
-            primary = np.stack(per_pass, 1).reshape(-1)
-            sample_slot = (np.arange(len(primary)) % passes) * n_slots + np.arange(len(primary)) // passes
+            primary_t = torch.stack(per_pass, 1).reshape(-1, 8).contiguous()
+            ar = torch.arange(len(primary_t), device=cdev)
+            sample_slot = (ar % passes) * n_slots + ar // passes
         else:                          # ray r = sample r // n_slots of slot r % n_slots
-            primary = np.concatenate(per_pass)
-            sample_slot = np.arange(len(primary))
-        n_primary = len(primary)
-        d_primary = dev(primary)
+            primary_t = torch.cat(per_pass)
+            sample_slot = torch.arange(len(primary_t), device=cdev)
+        del per_pass
+        n_primary = len(primary_t)
+        d_primary = primary_t.view(torch.uint8).reshape(-1)
         d_hits = torch.empty(n_primary * 32, dtype=torch.uint8, device=cdev)
         agg.intersect_device(d_primary.data_ptr(), d_hits.data_ptr(), n_primary, stream)
         torch.cuda.synchronize()
-        hits = d_hits.cpu().numpy().view(HIT_DTYPE)
-        bounce = scene.bounce_rays(primary, hits, verts, tris, seed=[2, rank, k])
+        bounce_t, hit_idx = ds.bounce_rays(primary_t, d_hits, seed=[2, rank, k])
         # bounce 2: the diffuse bounce of the bounce-1 hits (the incoherent regime)
-        d_bounce = dev(bounce)
-        d_bhits = torch.empty(len(bounce) * 32, dtype=torch.uint8, device=cdev)
-        agg.intersect_device(d_bounce.data_ptr(), d_bhits.data_ptr(), len(bounce), stream)
+        d_bounce = bounce_t.view(torch.uint8).reshape(-1)
+        d_bhits = torch.empty(len(bounce_t) * 32, dtype=torch.uint8, device=cdev)
+        agg.intersect_device(d_bounce.data_ptr(), d_bhits.data_ptr(), len(bounce_t), stream)
         torch.cuda.synchronize()
-        bhits0 = d_bhits.cpu().numpy().view(HIT_DTYPE)
-        bounce2 = scene.bounce_rays(bounce, bhits0, verts, tris, seed=[4, rank, k])
+        bounce2_t, _ = ds.bounce_rays(bounce_t, d_bhits, seed=[4, rank, k])
         if args.scene == "crown":  # towards the scene's six area-light quads (crown.pbrt:26-102)
-            shadow = scene.shadow_rays_to_quads(primary, hits, verts, tris, scene.CROWN_LIGHT_QUADS,
-                                                seed=[3, rank, k])
+            shadow_t, _ = ds.shadow_rays(primary_t, d_hits, seed=[3, rank, k], quads=scene.CROWN_LIGHT_QUADS)
         else:
-            shadow = scene.shadow_rays(primary, hits, verts, tris, lo + (hi - lo) * [0.3, 0.9, 0.3],
-                                       lo + (hi - lo) * [0.7, 1.0, 0.7], seed=[3, rank, k])
+            shadow_t, _ = ds.shadow_rays(primary_t, d_hits, seed=[3, rank, k],
+                                         box=(lo + (hi - lo) * [0.3, 0.9, 0.3], lo + (hi - lo) * [0.7, 1.0, 0.7]))
+        n_bounce, n_bounce2, n_shadow = len(bounce_t), len(bounce2_t), len(shadow_t)
         gen = torch.Generator(device=cdev).manual_seed(100 + 10 * rank + k)
+        first = k == 0
         st = {
-            "primary": primary if k == 0 else None, "bounce": bounce if k == 0 else None,
-            "bounce2": bounce2 if k == 0 else None,
-            "shadow": shadow if k == 0 else None, "hits": hits if k == 0 else None,
-            "n_primary": n_primary, "n_bounce": len(bounce), "n_bounce2": len(bounce2), "n_shadow": len(shadow),
-            "d_primary": d_primary, "d_hits": d_hits, "d_bounce": d_bounce, "d_shadow": dev(shadow),
-            "d_bhits": d_bhits, "d_bounce2": dev(bounce2),
-            "d_b2hits": torch.empty(len(bounce2) * 32, dtype=torch.uint8, device=cdev),
-            "d_occ": torch.empty(len(shadow), dtype=torch.uint8, device=cdev),
+            "primary": raygen.as_records(primary_t) if first else None,
+            "bounce": raygen.as_records(bounce_t) if first else None,
+            "bounce2": raygen.as_records(bounce2_t) if first else None,
+            "shadow": raygen.as_records(shadow_t) if first else None,
+            "hits": d_hits.cpu().numpy().view(HIT_DTYPE) if first else None,
+            "n_primary": n_primary, "n_bounce": n_bounce, "n_bounce2": n_bounce2, "n_shadow": n_shadow,
+            "d_primary": d_primary, "d_hits": d_hits, "d_bounce": d_bounce,
+            "d_shadow": shadow_t.view(torch.uint8).reshape(-1),
+            "d_bhits": d_bhits, "d_bounce2": bounce2_t.view(torch.uint8).reshape(-1),
+            "d_b2hits": torch.empty(n_bounce2 * 32, dtype=torch.uint8, device=cdev),
+            "d_occ": torch.empty(n_shadow, dtype=torch.uint8, device=cdev),
             # ShadowRayWorkItem payload (workitems.soa:77-83): Ld, r_u, r_l per shadow ray, the pixel
             # sample it belongs to; PixelSampleState::L per pixel sample (SampledSpectrum = 4 floats)
             # (index into L, which stays [pass][slot] whatever the order of the rays)
-            "d_pix": torch.from_numpy(sample_slot[hits["prim"] >= 0].astype(np.int32)).to(cdev),
-            "d_Ld": torch.rand((len(shadow), 4), generator=gen, device=cdev) * 2.0,
-            "d_ru": torch.rand((len(shadow), 4), generator=gen, device=cdev) + 0.5,
-            "d_rl": torch.rand((len(shadow), 4), generator=gen, device=cdev) + 0.5,
+            "d_pix": sample_slot[hit_idx].to(torch.int32),
+            "d_Ld": torch.rand((n_shadow, 4), generator=gen, device=cdev) * 2.0,
+            "d_ru": torch.rand((n_shadow, 4), generator=gen, device=cdev) + 0.5,
+            "d_rl": torch.rand((n_shadow, 4), generator=gen, device=cdev) + 0.5,
             "d_L": torch.zeros((n_primary, 4), dtype=torch.float32, device=cdev),
             "d_w": torch.rand(n_primary, generator=gen, device=cdev) + 0.5,  # filterWeight per sample
         }
+        del primary_t, bounce_t, bounce2_t, shadow_t, sample_slot, hit_idx
         sets.append(st)
     s0 = sets[0]
     rays_per_step = s0["n_primary"] + s0["n_bounce"] + s0["n_bounce2"] + s0["n_shadow"]
