@@ -424,6 +424,11 @@ inline int grid(long n) { return (int)((n + kB - 1) / kB); }
 bool gpu_kd_build(const float *prim_bounds, int n_prims, const float bounds[6], int isect_cost, int traversal_cost,
                   float empty_bonus, int max_prims, int max_depth, int device, KdGpuResult *out, std::string *error) {
     const auto t0 = std::chrono::steady_clock::now();
+    constexpr long kMaxRefs = 1L << 29;
+    if (n_prims > kMaxRefs) {
+        *error = "device kd build: more than 2^29 primitives";
+        return false;
+    }
     KG_CHECK(hipSetDevice(device), "hipSetDevice");
     hipStream_t stream = nullptr;
     const KdParamsBuild P{isect_cost, traversal_cost, max_prims, empty_bonus};
@@ -540,8 +545,8 @@ bool gpu_kd_build(const float *prim_bounds, int n_prims, const float bounds[6], 
                 *error = "device kd build: read-back failed";
                 return false;
             }
-            if ((long)nextRefs + totalBelow + totalAbove > 0x7fffffffL / 2) {
-                *error = "device kd build: more than 2^30 primitive references on one level";
+            if ((long)nextRefs + totalBelow + totalAbove > kMaxRefs) {  // 2 edges per reference, int32 scans
+                *error = "device kd build: more than 2^29 primitive references on one level";
                 return false;
             }
             KG_ALLOC(*nextSegs, (size_t)nextSeg + 2 * (size_t)nInterior, true);
