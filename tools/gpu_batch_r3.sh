@@ -1,11 +1,6 @@
 set -u
-mkdir -p gpurun_out/r3o
-(timeout -k 10 400 python -m pytest tests/test_bench_contract.py tests/test_raygen.py -m "gpu or not gpu" -x -q > gpurun_out/r3o/gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/r3o/gpu.log; grep -v "^Extension" gpurun_out/r3o/gpu.log | tail -3)
-timeout -k 10 300 python bench.py > gpurun_out/r3o/bench.json 2> gpurun_out/r3o/bench.err; tail -3 gpurun_out/r3o/bench.err; cut -c1-200 gpurun_out/r3o/bench.json
-tools/profile_bench.sh gpurun_out/r3o/final --sample-sets 2 > gpurun_out/r3o/final.log 2>&1
-python3 tools/prof_summary.py gpurun_out/r3o/final gpurun_out/r3o/final/summary.json --meta workload=bench_default spp=8 > gpurun_out/r3o/final.summary.txt 2>&1
-cp $(find gpurun_out/r3o/final/kt -name "*kernel_stats.csv" | head -1) gpurun_out/r3o/final/kernel_stats.csv
-for d in rdreq write sq1 sq2 tcc fetch tcp kt; do rm -rf gpurun_out/r3o/final/$d; done
-grep "trace_kernel<3" gpurun_out/r3o/final.summary.txt | cut -c1-500
-timeout -k 10 200 python bench.py --scene killeroos --steps 5 --warmup 1 --sample-sets 2 > gpurun_out/r3o/bench_killeroos.json 2> gpurun_out/r3o/bench_killeroos.err; cut -c1-160 gpurun_out/r3o/bench_killeroos.json
-timeout -k 10 200 python bench.py --scene bathroom --steps 5 --warmup 1 --sample-sets 2 > gpurun_out/r3o/bench_bathroom.json 2> gpurun_out/r3o/bench_bathroom.err; cut -c1-160 gpurun_out/r3o/bench_bathroom.json
+mkdir -p gpurun_out/r3p
+(timeout -k 10 700 python -m pytest tests -m gpu -x -q > gpurun_out/r3p/gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/r3p/gpu.log; grep -v "^Extension" gpurun_out/r3p/gpu.log | tail -3)
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r3p/smoke.log 2>&1; tail -1 gpurun_out/r3p/smoke.log
+timeout -k 10 300 python bench.py > gpurun_out/r3p/bench.json 2> gpurun_out/r3p/bench.err; tail -2 gpurun_out/r3p/bench.err; cut -c1-200 gpurun_out/r3p/bench.json
+NNBVH_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 3 --warmup 1 --sample-sets 1 --no-cpu-baseline > gpurun_out/r3p/bench_2rank_gloo.json 2> gpurun_out/r3p/bench_2rank_gloo.err; tail -2 gpurun_out/r3p/bench_2rank_gloo.err; cut -c1-200 gpurun_out/r3p/bench_2rank_gloo.json
