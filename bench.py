@@ -131,7 +131,7 @@ def self_launch(n_gpus):
     return subprocess.run(cmd, env=env).returncode
 
 
-def dry_run(args, rank, world):
+def dry_run(args, rank, world, out=sys.stdout):
     """NNBVH_BENCH_DRYRUN=1: rendezvous only (gloo, no GPU) — the CPU test of the launch path."""
     import torch
     import torch.distributed as dist
@@ -147,7 +147,7 @@ def dry_run(args, rank, world):
         total = 1.0
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": total, "steps": args.steps,
-                          "warmup": args.warmup}), flush=True)
+                          "warmup": args.warmup}), file=out, flush=True)
     return 0
 
 
@@ -193,8 +193,15 @@ def main():
     if world != args.gpus:
         log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
         sys.exit(2)
+    # stdout carries ONE line, the result: whatever libraries print there (RCCL's and gloo's start-up banners)
+    # goes to stderr instead — file descriptor 1 is pointed at stderr and the result is written to the real stdout
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    result_out = os.fdopen(result_fd, "w")
     if os.environ.get("NNBVH_BENCH_DRYRUN") == "1":
-        sys.exit(dry_run(args, rank, world))
+        rc = dry_run(args, rank, world, result_out)
+        sys.exit(rc)
 
     import numpy as np
     import torch
@@ -805,7 +812,7 @@ def main():
                                             "(BASELINE.md §2): survey container, not this box"),
         }
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=result_out, flush=True)
     film.close()
     agg.close()
     if world > 1:
