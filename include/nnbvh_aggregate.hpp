@@ -19,11 +19,18 @@
 // A per-ray Intersect() is a batch of one: correct, and three orders of magnitude slower
 // than the batched calls (a kernel launch per ray).  It exists so that the CPU integrators
 // can call the aggregate "unchanged" for validation; production callers batch.
+// CoalescingAggregate<> is the middle way for those integrators: the rays of the many threads of
+// pbrt's ParallelFor2D (util/parallel.cpp:301-330) that are inside Intersect() at the same moment are
+// traced as ONE batch.
 #pragma once
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <optional>
 #include <string>
 #include <vector>
@@ -381,6 +388,118 @@ class HipFilm {
   private:
     nnbvh_film *film_ = nullptr;
     int64_t nPixels_ = 0;
+};
+
+// ---- per-ray calls from many threads, traced together ------------------------------------------------
+// pbrt's CPU integrators call Primitive::Intersect / IntersectP once per ray from every thread of ParallelFor2D
+// (cpu/integrators.cpp:152-216, 296-313).  CoalescingAggregate keeps that call shape — Intersect(ray, tMax)
+// blocks and returns this ray's result — and turns the rays that are in flight at the same moment into one
+// batch: a caller appends its ray to the open batch and waits; the caller that fills the batch (maxBatch) or the
+// first one whose wait exceeds maxWait becomes the leader, closes the batch, traces it with one
+// IntersectClosest / IntersectShadow call and wakes the others.  Rays arriving while the leader is on the GPU
+// open the next batch.  Results are exactly the batched calls' (rays are independent).  A: HipBVHAggregate or
+// HipKdTreeAggregate.
+template <typename A>
+class CoalescingAggregate {
+  public:
+    explicit CoalescingAggregate(const A &aggregate, size_t maxBatch = 4096,
+                                 std::chrono::microseconds maxWait = std::chrono::microseconds(50))
+        : agg_(aggregate), maxBatch_(maxBatch), maxWait_(maxWait) {}
+
+    Bounds3f Bounds() const { return agg_.Bounds(); }
+
+    std::optional<HitRecord> Intersect(const Ray &ray, float tMax = std::numeric_limits<float>::infinity(),
+                                       bool *needsHost = nullptr) {
+        const nnbvh_hit h = submit(closest_, wire(ray, tMax)).hit;
+        if (needsHost) *needsHost = h.instance == -1;
+        if (h.instance == -1) {
+            if (!needsHost) HipBVHAggregate::fatal("CoalescingAggregate::Intersect: the ray met a host-only primitive (pass needsHost)");
+            return {};
+        }
+        if (h.prim < 0) return {};
+        return HitRecord{h.prim, h.t, h.b0, h.b1, h.b2, h.instance};
+    }
+    bool IntersectP(const Ray &ray, float tMax = std::numeric_limits<float>::infinity(), bool *needsHost = nullptr) {
+        const uint8_t occ = submit(shadow_, wire(ray, tMax)).occluded;
+        if (needsHost) *needsHost = occ == 2;
+        if (occ == 2 && !needsHost) HipBVHAggregate::fatal("CoalescingAggregate::IntersectP: the ray met a host-only primitive (pass needsHost)");
+        return occ == 1;
+    }
+    // batches traced so far and the rays in them (closest + shadow)
+    void Stats(uint64_t *batches, uint64_t *rays) const {
+        std::lock_guard<std::mutex> lock(closest_.m);
+        std::lock_guard<std::mutex> lock2(shadow_.m);
+        *batches = closest_.batches + shadow_.batches;
+        *rays = closest_.rays + shadow_.rays;
+    }
+
+  private:
+    struct Result {
+        nnbvh_hit hit;
+        uint8_t occluded;
+    };
+    struct Batch {
+        std::vector<nnbvh_ray> rays;
+        std::vector<nnbvh_hit> hits;
+        std::vector<uint8_t> occluded;
+        bool closed = false, done = false;
+    };
+    struct Lane {  // one kind of query (closest hit / any hit)
+        bool shadow;
+        mutable std::mutex m;
+        std::condition_variable cv;
+        std::shared_ptr<Batch> open;
+        uint64_t batches = 0, rays = 0;
+    };
+    static nnbvh_ray wire(const Ray &ray, float tMax) {
+        return nnbvh_ray{{ray.o.x, ray.o.y, ray.o.z}, tMax, {ray.d.x, ray.d.y, ray.d.z}, ray.time};
+    }
+    Result submit(Lane &L, const nnbvh_ray &r) {
+        std::unique_lock<std::mutex> lock(L.m);
+        if (!L.open) L.open = std::make_shared<Batch>();
+        std::shared_ptr<Batch> b = L.open;
+        const size_t index = b->rays.size();
+        b->rays.push_back(r);
+        bool lead = b->rays.size() >= maxBatch_;
+        if (!lead) {
+            // wait to be traced by someone else; the first waiter to time out leads
+            const auto deadline = std::chrono::steady_clock::now() + maxWait_;
+            while (!b->done && !b->closed) {
+                if (L.cv.wait_until(lock, deadline) == std::cv_status::timeout && !b->closed && !b->done) {
+                    lead = true;
+                    break;
+                }
+            }
+            while (!lead && !b->done) L.cv.wait(lock);
+        }
+        if (lead) {
+            b->closed = true;
+            if (L.open == b) L.open.reset();  // later rays open the next batch
+            lock.unlock();
+            const int64_t n = (int64_t)b->rays.size();
+            if (L.shadow) {
+                b->occluded.resize((size_t)n);
+                agg_.IntersectShadow(b->rays.data(), n, b->occluded.data());
+            } else {
+                b->hits.resize((size_t)n);
+                agg_.IntersectClosest(b->rays.data(), n, b->hits.data());
+            }
+            lock.lock();
+            b->done = true;
+            L.batches += 1;
+            L.rays += (uint64_t)n;
+            L.cv.notify_all();
+        }
+        Result out{};
+        if (L.shadow) out.occluded = b->occluded[index];
+        else out.hit = b->hits[index];
+        return out;
+    }
+
+    const A &agg_;
+    size_t maxBatch_;
+    std::chrono::microseconds maxWait_;
+    Lane closest_{false}, shadow_{true};
 };
 
 }  // namespace nnbvh

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "nnbvh_aggregate.hpp"
@@ -115,6 +116,33 @@ int main() {
         (void)k2.Intersect(through);
         nnbvh::HipBVHAggregate::fatal_handler() = prev;
         if (fatals != 2) return 26;
+    }
+    // per-ray calls from many threads (the CPU integrators' shape), coalesced into batches: every thread gets
+    // exactly the batched results, and far fewer batches than rays were launched
+    {
+        nnbvh::CoalescingAggregate<nnbvh::HipBVHAggregate> co(agg, 64, std::chrono::microseconds(200));
+        const int nThreads = 8;
+        std::vector<int> bad(nThreads, 0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nThreads; ++t)
+            pool.emplace_back([&, t] {
+                for (int rep = 0; rep < 4; ++rep)
+                    for (int i = t; i < nRays; i += nThreads) {
+                        nnbvh::Ray ray{{rays[i].o[0], rays[i].o[1], rays[i].o[2]}, {rays[i].d[0], rays[i].d[1], rays[i].d[2]}, 0};
+                        auto si = co.Intersect(ray);
+                        if (si.has_value() != (hits[i].prim >= 0)) ++bad[t];
+                        else if (si && (si->prim != hits[i].prim || std::memcmp(&si->tHit, &hits[i].t, 4))) ++bad[t];
+                        if (co.IntersectP(ray) != (occ[i] != 0)) ++bad[t];
+                    }
+            });
+        for (auto &th : pool) th.join();
+        for (int t = 0; t < nThreads; ++t)
+            if (bad[t]) return 30;
+        uint64_t batches = 0, traced = 0;
+        co.Stats(&batches, &traced);
+        if (traced != 2ull * 4 * nRays) return 31;
+        if (batches * 2 > traced) return 32;  // on average more than two rays per launch
+        std::printf("coalesced: %llu rays in %llu batches\n", (unsigned long long)traced, (unsigned long long)batches);
     }
     // the film: an empty film reads back as zeros (accumulation itself: tests/test_film.py)
     nnbvh::HipFilm film(0, 0, 8, 4);

@@ -13,7 +13,7 @@ def _build(nnbvh_lib):
     src = os.path.join(ROOT, "tests", "cpp", "adapter_check.cpp")
     libdir = os.path.join(ROOT, "nn_bvh_amd")
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
-                    src, "-o", EXE, "-L", libdir, "-l:libnnbvh_hip.so", f"-Wl,-rpath,{libdir}",
+                    src, "-o", EXE, "-pthread", "-L", libdir, "-l:libnnbvh_hip.so", f"-Wl,-rpath,{libdir}",
                     "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
 
 
