@@ -1,4 +1,5 @@
 set -u
-mkdir -p gpurun_out/r3r
-(timeout -k 10 300 python -m pytest tests/test_cpp_adapter.py -m gpu -x -q > gpurun_out/r3r/gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/r3r/gpu.log; grep -v "^Extension" gpurun_out/r3r/gpu.log | tail -8)
-tests/cpp/adapter_check
+mkdir -p gpurun_out/r3s
+for v in "" _prio1 _prio2 _prio3 ""; do
+  NNBVH_LIB=libnnbvh_hip$v.so timeout -k 10 150 python tools/batch_order_probe.py > gpurun_out/r3s/prio$v.txt 2>&1; echo "== lib$v"; grep "S B2 B1 P\|P B1 B2 S" gpurun_out/r3s/prio$v.txt
+done
