@@ -10,7 +10,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "libnnbvh_oracle.so")
+# NNBVH_ORACLE_LIB: a diagnostic build of the same source (tools/asan_cpu.sh)
+ORACLE_LIB = os.environ.get("NNBVH_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libnnbvh_oracle.so")
 
 _lib = None
 
