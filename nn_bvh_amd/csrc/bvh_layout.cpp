@@ -64,12 +64,71 @@ void place_pairs_dfs(const std::vector<WideNode> &w, int root, PairAlloc &al, st
     }
 }
 
+// mode 32 (experiment, NNBVH_FAT builds of the lean kernel instances only): 192-B "fat" records — a node's own
+// record followed by COPIES of its two children's records, so that one trip to memory serves the node and the
+// child the ray enters next (the reference's binary order replayed from the copy: same boxes, same arithmetic,
+// same counts).  Interior references become (record << 2) | axis of the referenced node: which copy a ray needs
+// (its near child's, aggregates.cpp:562-568) is then known before the record arrives.
+bool fatten_scene(float4 **d_wide, float4 **d_prims, int *n_interior, int64_t *n_slots, int *root_ref,
+                  std::string *error) {
+    const int n = *n_interior;
+    const int64_t ns = *n_slots;
+    if (n <= 0 || *root_ref < 0) return true;
+    if (n >= (1 << 22)) {
+        *error = "fat records: more than 2^22 interior records (192-B records behind 32-bit offsets)";
+        return false;
+    }
+    std::vector<WideNode> w((size_t)n);
+    std::vector<float4> stream((size_t)ns);
+    auto fail = [&](const char *what, hipError_t e) {
+        *error = std::string("fat records: ") + what + ": " + hipGetErrorString(e);
+        return false;
+    };
+    hipError_t e = hipMemcpy(w.data(), *d_wide, (size_t)n * sizeof(WideNode), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail("read records", e);
+    e = hipMemcpy(stream.data(), *d_prims, (size_t)ns * 16, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail("read stream", e);
+    auto enc = [&](int ref) { return ref >= 0 ? ((ref << 2) | (w[(size_t)ref].axis & 3)) : ref; };
+    std::vector<WideNode> fat((size_t)n * 3);
+    std::memset(fat.data(), 0, fat.size() * sizeof(WideNode));
+    for (int i = 0; i < n; ++i) {
+        WideNode r = w[(size_t)i];
+        r.ref0 = enc(w[(size_t)i].ref0);
+        r.ref1 = enc(w[(size_t)i].ref1);
+        fat[(size_t)i * 3] = r;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 2; ++c) {
+            const int ref = c ? w[(size_t)i].ref1 : w[(size_t)i].ref0;
+            if (ref >= 0) fat[(size_t)i * 3 + 1 + c] = fat[(size_t)ref * 3];
+        }
+    const size_t wideBytes = (fat.size() * sizeof(WideNode) + 255) & ~(size_t)255;
+    void *arena = nullptr;
+    e = hipMalloc(&arena, wideBytes + (size_t)ns * 16 + 64);
+    if (e != hipSuccess) return fail("hipMalloc", e);
+    char *ps = (char *)arena + wideBytes;
+    e = hipMemcpy(arena, fat.data(), fat.size() * sizeof(WideNode), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ps, stream.data(), (size_t)ns * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(ps + (size_t)ns * 16, 0, 64);
+    if (e != hipSuccess) {
+        (void)hipFree(arena);
+        return fail("upload", e);
+    }
+    (void)hipFree(*d_wide);
+    *d_wide = (float4 *)arena;
+    *d_prims = (float4 *)ps;
+    *n_interior = 3 * n;  // records of 64 B the allocation holds (sizes, the 4-GiB check)
+    *root_ref = enc(*root_ref);
+    return true;
+}
+
 }  // namespace
 
 // Returns false (error set) on a device error; otherwise *d_wide / *d_prims / *n_interior / *n_slots
 // describe the new allocation (records, 256-B aligned stream, 64 B padding) and the old one is freed.
 bool relayout_scene(int mode, float4 **d_wide, float4 **d_prims, int *n_interior, int64_t *n_slots, int *root_ref,
                     int top_levels, std::string *error) {
+    if (mode == 32) return fatten_scene(d_wide, d_prims, n_interior, n_slots, root_ref, error);
     const int recMode = mode & 15;
     const bool alignLeaves = (mode & 16) != 0;
     if (recMode == 0 && !alignLeaves) return true;

@@ -92,6 +92,9 @@ constexpr int kEnter = (int)0x80000002;   // INST = 2: the lane waits to enter a
 #ifndef NNBVH_MERGED
 #define NNBVH_MERGED 0
 #endif
+#ifndef NNBVH_FAT
+#define NNBVH_FAT 0
+#endif
 //
 // INST = 1: the scene is two-level (TransformedPrimitive leaves, cpu/primitive.cpp:112-131).  An
 // instance primitive saves the lane's ray state in LDS, transforms the ray with the reference's
@@ -420,11 +423,30 @@ void trace_kernel(TraceParams p) {
             // lean instances address records and slots with a 32-bit byte offset from a scalar base (one
             // 32-bit shift instead of a 64-bit shift and a 64-bit add per fetch); the launcher only picks
             // them when both arrays are below 4 GiB (p.fits32)
+            if constexpr (NNBVH_FAT && kLean) {
+            // experiment (bvh_layout.cpp mode 32): 192-B records = the node's own record + copies of both
+            // children's; the copy of the child this ray enters next arrives with the node's record, and the
+            // lanes that do enter it (and find it interior) take that step in the same trip
+            const unsigned at = ((unsigned)cur >> 2) * 192u;
+            const unsigned nearCopy = 64u + (((unsigned)r.kz >> (cur & 3)) & 1u) * 64u;
+            const float4 *rec = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.wide) + at);
+            const float4 *rec2 = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.wide) + at + nearCopy);
+            const float4 q3 = rec[3];
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            const float4 n3 = rec2[3];
+            const float4 n0 = rec2[0], n1 = rec2[1], n2 = rec2[2];
+            const int nearChild = (((unsigned)r.kz >> (cur & 3)) & 1u) ? __float_as_int(q3.y) : __float_as_int(q3.x);
+            interior_math(q0, q1, q2, q3);
+            // the near child was entered iff the lane now stands on it; a popped entry with the same
+            // reference cannot exist (a node has one parent and is pushed at most once)
+            if (cur >= 0 && cur == nearChild) interior_math(n0, n1, n2, n3);
+            } else {
             const float4 *rec = kLean ? reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.wide) + ((unsigned)cur << 6))
                                       : p.wide + 4 * (long)cur;
             const float4 q3 = rec[3];
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
             interior_math(q0, q1, q2, q3);
+            }
         }
     };
 
