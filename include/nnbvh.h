@@ -80,6 +80,18 @@ typedef struct nnbvh_linear_node {
                                        (nnbvh_scene_create_with_normals).  BVH scenes; inside a kd-tree
                                        such primitives stay NNBVH_PRIM_HOST */
 #define NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED 7
+#define NNBVH_PRIM_ALPHA_PATCH 8   /* BilinearPatch behind a GeometricPrimitive with a CONSTANT alpha (v[0..3] are the
+                                       patch's vertices: the alpha comes from the per-primitive array of
+                                       nnbvh_scene_create_with_attributes).  A non-planar patch can be met again by the
+                                       ray re-traced off its own surface; the recursion of cpu/primitive.cpp:63-69 is
+                                       followed for up to three re-traces, beyond which the record is void
+                                       (needs-host).  For patch meshes WITHOUT (u, v) coordinates — with them the
+                                       geometric normal goes through the (s, t) reparametrisation of shapes.h:
+                                       1414-1437 and the primitive stays NNBVH_PRIM_HOST.  BVH scenes, single level */
+#define NNBVH_PRIM_ALPHA_PATCH_FLIPPED 9         /* same, mesh->reverseOrientation ^ transformSwapsHandedness */
+#define NNBVH_PRIM_ALPHA_PATCH_SMOOTH 10         /* ... of a mesh WITH per-vertex normals (BilinearPatchMesh::n as
+                                                     the mesh stores them, util/mesh.cpp:216-223) */
+#define NNBVH_PRIM_ALPHA_PATCH_SMOOTH_FLIPPED 11
 
 /* One entry of BVHAggregate::primitives: the shape handle flattened to global vertex
  * indices (Triangle{meshIndex,triIndex} -> mesh->vertexIndices[3*tri..], shapes.cpp:326-328). */
@@ -228,6 +240,12 @@ nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, 
 nnbvh_scene *nnbvh_scene_create_with_normals(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
                                              int n_prims, const float *verts, const float *normals, int n_verts,
                                              int device);
+/* ... and with a per-primitive constant alpha (n_prims floats, indexed like `prims`): read for the
+ * NNBVH_PRIM_ALPHA_PATCH* primitives only (alpha-tested triangles keep theirs in v[3]).  Either array may be NULL
+ * when no primitive needs it. */
+nnbvh_scene *nnbvh_scene_create_with_attributes(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
+                                                int n_prims, const float *verts, const float *normals,
+                                                const float *prim_alpha, int n_verts, int device);
 void nnbvh_scene_destroy(nnbvh_scene *s);
 int nnbvh_scene_bounds(const nnbvh_scene *s, float out_min_max[6]);
 /* what the baked device layout looks like: [0]=interior records, [1]=prim-stream slots,

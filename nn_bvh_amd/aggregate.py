@@ -117,13 +117,14 @@ class BVHAggregate:
 
     @classmethod
     def from_tree(cls, nodes, ordered_prims, verts, device=0, instances=None, n_top_nodes=None, animated=None,
-                  normals=None):
+                  normals=None, prim_alpha=None):
         """instances (INSTANCE_DTYPE) + n_top_nodes make a two-level scene: nodes[:n_top_nodes] is
         the top-level tree, the child trees follow (see nn_bvh_amd.instancing).  animated
         (ANIMATED_DTYPE, one per instance) turns instances into AnimatedPrimitives.  normals: per-vertex
-        shading normals, needed by alpha-tested triangles of smooth meshes (prim kinds 6 / 7)."""
+        shading normals, needed by alpha-tested triangles / patches of smooth meshes (prim kinds 6 / 7, 10 / 11);
+        prim_alpha: one constant alpha per entry of ordered_prims, read for alpha-tested patches (kinds 8 .. 11)."""
         self = cls.__new__(cls)
-        self._init(nodes, ordered_prims, verts, device, None, instances, n_top_nodes, animated, normals)
+        self._init(nodes, ordered_prims, verts, device, None, instances, n_top_nodes, animated, normals, prim_alpha)
         return self
 
     @classmethod
@@ -161,7 +162,7 @@ class BVHAggregate:
                      "grid_blocks": int(info[4]), "stack_window": int(info[5])}
 
     def _init(self, nodes, ordered_prims, verts, device, depth, instances=None, n_top_nodes=None, animated=None,
-              normals=None):
+              normals=None, prim_alpha=None):
         L = _lib.lib()
         self.nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
         self.ordered_prims = np.ascontiguousarray(ordered_prims, PRIM_DTYPE)
@@ -181,6 +182,15 @@ class BVHAggregate:
                     ptr(self.nodes), len(self.nodes), int(n_top_nodes), ptr(self.ordered_prims),
                     len(self.ordered_prims), ptr(self.verts), len(self.verts), ptr(self.instances),
                     len(self.instances), self.device)
+        elif prim_alpha is not None:
+            self.normals = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+            self.prim_alpha = np.ascontiguousarray(prim_alpha, np.float32).reshape(-1)
+            assert len(self.prim_alpha) == len(self.ordered_prims)
+            assert self.normals is None or len(self.normals) == len(self.verts)
+            self._h = L.nnbvh_scene_create_with_attributes(
+                ptr(self.nodes), len(self.nodes), ptr(self.ordered_prims), len(self.ordered_prims), ptr(self.verts),
+                ptr(self.normals) if self.normals is not None else None, ptr(self.prim_alpha), len(self.verts),
+                self.device)
         elif normals is not None:
             self.normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
             assert len(self.normals) == len(self.verts)

@@ -36,6 +36,10 @@ __global__ __launch_bounds__(kBk) void k_bake_slot_counts(const nnbvh_prim *__re
         c = 6;  // three slots of vertex normals follow the triangle's
         atomicOr(flags, 8 | 16);
     }
+    else if (is_alpha_patch_kind(kind)) {
+        c = is_smooth_alpha_patch_kind(kind) ? 8 : 4;  // four slots of vertex normals follow the patch's
+        atomicOr(flags, 4 | 8 | 32 | (is_smooth_alpha_patch_kind(kind) ? 16 : 0));
+    }
     else if (kind != NNBVH_PRIM_TRIANGLE) atomicOr(flags, 2);  // instances are not baked here
     slots[i] = c;
 }
@@ -61,6 +65,7 @@ __device__ __forceinline__ float bake_dop(float a, float b, float c, float d) {
 __global__ __launch_bounds__(kBk) void k_bake_stream(const nnbvh_prim *__restrict__ prims, int n,
                                                     const float *__restrict__ verts,
                                                     const float *__restrict__ normals,
+                                                    const float *__restrict__ primAlpha,
                                                     const int *__restrict__ slotOf,
                                                     const unsigned char *__restrict__ leafLast,
                                                     float4 *__restrict__ stream) {
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(kBk) void k_bake_stream(const nnbvh_prim *__restric
         s[2] = make_float4(0, 0, 0, 0);
         return;
     }
-    const int nv = p.kind == NNBVH_PRIM_BILINEAR_PATCH ? 4 : 3;
+    const int nv = (p.kind == NNBVH_PRIM_BILINEAR_PATCH || is_alpha_patch_kind(p.kind)) ? 4 : 3;
     float v[4][3];
     for (int j = 0; j < nv; ++j)
         for (int k = 0; k < 3; ++k) v[j][k] = verts[3 * (long)p.v[j] + k];
@@ -98,6 +103,15 @@ __global__ __launch_bounds__(kBk) void k_bake_stream(const nnbvh_prim *__restric
         alpha = __int_as_float(p.v[3]);
         for (int j = 0; j < 3; ++j)
             s[3 + j] = make_float4(normals[3 * (long)p.v[j]], normals[3 * (long)p.v[j] + 1], normals[3 * (long)p.v[j] + 2], 0);
+    }
+    if (is_alpha_patch_kind(p.kind)) {
+        flags |= kPrimAlpha | (is_flipped_alpha_patch_kind(p.kind) ? kPrimFlipN : 0u);
+        alpha = primAlpha[i];
+        if (is_smooth_alpha_patch_kind(p.kind)) {
+            flags |= kPrimSmooth;
+            for (int j = 0; j < 4; ++j)
+                s[4 + j] = make_float4(normals[3 * (long)p.v[j]], normals[3 * (long)p.v[j] + 1], normals[3 * (long)p.v[j] + 2], 0);
+        }
     }
     s[0] = make_float4(v[0][0], v[0][1], v[0][2], __int_as_float(p.id));
     s[1] = make_float4(v[1][0], v[1][1], v[1][2], __uint_as_float(flags));
@@ -151,7 +165,7 @@ struct Scratch {
     } while (0)
 
 bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int n_prims, const void *d_verts_,
-                    int device, BakedScene *out, std::string *error, const void *d_normals_) {
+                    int device, BakedScene *out, std::string *error, const void *d_normals_, const void *d_prim_alpha_) {
     const auto *dNodes = (const nnbvh_linear_node *)d_nodes_;
     const auto *dPrims = (const nnbvh_prim *)d_prims_;
     const auto *dVerts = (const float *)d_verts_;
@@ -196,8 +210,13 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
         return false;
     }
     if ((flags & 16) && !d_normals_) {
-        *error = "scene_create: NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH primitives need the vertex normals "
+        *error = "scene_create: smooth alpha-tested primitives need the vertex normals "
                  "(nnbvh_scene_create_with_normals)";
+        return false;
+    }
+    if ((flags & 32) && !d_prim_alpha_) {
+        *error = "scene_create: NNBVH_PRIM_ALPHA_PATCH primitives need the per-primitive alpha array "
+                 "(nnbvh_scene_create_with_attributes)";
         return false;
     }
     if (nSlots <= 0 || nSlots >= 0x7ffffffe) {
@@ -212,7 +231,7 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
     BK_CHECK(hipMalloc(&dWide, wideBytes + (size_t)nSlots * 16 + 64), "hipMalloc(nodes + primitives)");
     dStream = (char *)dWide + wideBytes;
     BK_CHECK(hipMemsetAsync((char *)dStream + (size_t)nSlots * 16, 0, 64, stream), "memset");
-    hipLaunchKernelGGL(k_bake_stream, dim3(gp), dim3(kBk), 0, stream, dPrims, n_prims, dVerts, (const float *)d_normals_, dSlotOf, dLeafLast,
+    hipLaunchKernelGGL(k_bake_stream, dim3(gp), dim3(kBk), 0, stream, dPrims, n_prims, dVerts, (const float *)d_normals_, (const float *)d_prim_alpha_, dSlotOf, dLeafLast,
                        (float4 *)dStream);
     hipLaunchKernelGGL(k_bake_wide, dim3(gn), dim3(kBk), 0, stream, dNodes, n_nodes, dOrd, dSlotOf, (float4 *)dWide);
     int rootSlot = 0;
@@ -234,7 +253,7 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
     std::memcpy(out->bounds + 3, root.pmax, 12);
     out->has_host_prims = flags & 1;
     out->has_patches = (flags & 4) ? 1 : 0;
-    out->has_alpha = (flags & 8) ? 1 : 0;
+    out->has_alpha = (flags & 32) ? 2 : ((flags & 8) ? 1 : 0);  // 2: alpha-tested PATCHES present (the ALPHA = 2 kernels)
     return true;
 }
 

@@ -522,7 +522,7 @@ nnbvh_build *nnbvh_build_create_with_bounds(const nnbvh_prim *prims, int n_prims
     std::vector<BuildPrim> bp((size_t)n_prims);
     for (int i = 0; i < n_prims; ++i) {
         const nnbvh_prim &p = prims[i];
-        int nv = nnbvh::is_triangle_kind(p.kind) ? 3 : p.kind == NNBVH_PRIM_BILINEAR_PATCH ? 4 : 0;
+        int nv = nnbvh::is_triangle_kind(p.kind) ? 3 : (p.kind == NNBVH_PRIM_BILINEAR_PATCH || nnbvh::is_alpha_patch_kind(p.kind)) ? 4 : 0;
         bp[i].index = (size_t)i;
         if (p.kind == NNBVH_PRIM_INSTANCE || p.kind == NNBVH_PRIM_HOST) {
             // TransformedPrimitive::Bounds() = renderFromPrimitive(child bounds) / the host

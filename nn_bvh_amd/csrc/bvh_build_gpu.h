@@ -65,6 +65,7 @@ struct BakedScene {
 // d_normals: per-vertex shading normals (3 floats, indexed like the vertices) or null; read for
 // NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH primitives only
 bool bake_on_device(const void *d_nodes, int n_nodes, const void *d_ordered_prims, int n_prims, const void *d_verts,
-                    int device, BakedScene *out, std::string *error, const void *d_normals = nullptr);
+                    int device, BakedScene *out, std::string *error, const void *d_normals = nullptr,
+                    const void *d_prim_alpha = nullptr);
 
 }  // namespace nnbvh

@@ -95,7 +95,7 @@ struct nnbvh_scene {
     int instanced = 0;      // two-level scene: use the INST kernels
     int has_host_prims = 0;
     int has_patches = 1;    // 0: no bilinear patches, the lean kernels (no ray direction parked in LDS) run
-    int has_alpha = 0;      // alpha-tested triangles present: the ALPHA kernels run
+    int has_alpha = 0;      // 1: alpha-tested triangles present (the ALPHA kernels run), 2: alpha-tested patches too
     int fused_batches = 1;  // nnbvh_trace_batches_device: one mode-3 launch where the batches allow it
     int int_repeat = 3;
     int prim_repeat = 2;
@@ -263,8 +263,8 @@ static nnbvh_scene *scene_from_baked(const BakedScene &b, int depth, int device)
     std::memcpy(s->bounds, b.bounds, sizeof b.bounds);
     s->root_ref = b.root_ref;
     s->instanced = 0;
-    s->has_host_prims = b.has_host_prims | b.has_alpha;
-    s->has_patches = b.has_patches | b.has_alpha;  // the alpha test hashes the ray direction, parked with the patches' one
+    s->has_host_prims = (b.has_host_prims || b.has_alpha) ? 1 : 0;
+    s->has_patches = (b.has_patches || b.has_alpha) ? 1 : 0;  // the alpha test hashes the ray direction, parked with the patches' one
     s->has_alpha = b.has_alpha;
     s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
     s->d_wide = (float4 *)b.d_wide;
@@ -299,7 +299,7 @@ static nnbvh_scene *scene_from_baked(const BakedScene &b, int depth, int device)
 // and primitive).
 static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
                                              int n_prims, const float *verts, int n_verts, int depth, int device,
-                                             const float *normals) {
+                                             const float *normals, const float *prim_alpha) {
     int n_dev = nnbvh_device_count();
     if (n_dev <= 0 || device < 0 || device >= n_dev) {
         set_error("scene_create: no usable HIP device (this library has no CPU fallback)");
@@ -307,7 +307,7 @@ static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int
     }
     DeviceGuard guard(device);
     if (!guard.ok) return nullptr;
-    void *d_nodes = nullptr, *d_prims = nullptr, *d_verts = nullptr, *d_normals = nullptr;
+    void *d_nodes = nullptr, *d_prims = nullptr, *d_verts = nullptr, *d_normals = nullptr, *d_alpha = nullptr;
     const size_t nb = (size_t)n_nodes * sizeof(nnbvh_linear_node), pbytes = (size_t)n_prims * sizeof(nnbvh_prim),
                  vb = (size_t)n_verts * 12;
     BakedScene b;
@@ -320,11 +320,14 @@ static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int
     if (ok && normals)
         ok = hip_ok(hipMalloc(&d_normals, vb), "hipMalloc(normals)") &&
              hip_ok(hipMemcpy(d_normals, normals, vb, hipMemcpyHostToDevice), "hipMemcpy(normals)");
-    if (ok && !bake_on_device(d_nodes, n_nodes, d_prims, n_prims, d_verts, device, &b, &err, d_normals)) {
+    if (ok && prim_alpha)
+        ok = hip_ok(hipMalloc(&d_alpha, (size_t)n_prims * 4), "hipMalloc(primitive alpha)") &&
+             hip_ok(hipMemcpy(d_alpha, prim_alpha, (size_t)n_prims * 4, hipMemcpyHostToDevice), "hipMemcpy(primitive alpha)");
+    if (ok && !bake_on_device(d_nodes, n_nodes, d_prims, n_prims, d_verts, device, &b, &err, d_normals, d_alpha)) {
         set_error(err);
         ok = false;
     }
-    for (void *p : {d_nodes, d_prims, d_verts, d_normals})
+    for (void *p : {d_nodes, d_prims, d_verts, d_normals, d_alpha})
         if (p) (void)hipFree(p);
     return ok ? scene_from_baked(b, depth, device) : nullptr;
 }
@@ -342,6 +345,10 @@ static float quat_angle_between_host(const float q1[4], const float q2[4]) {
     x = x < -1 ? -1 : (x > 1 ? 1 : x);
     return neg ? 3.14159265358979323846f - 2 * std::asin(x) : 2 * std::asin(x);
 }
+// launch_trace's `patches`: bit 0 patches (or alpha: the parked ray direction), bit 1 alpha-tested triangles,
+// bit 2 alpha-tested patches
+static int patch_bits(const nnbvh_scene *s) { return s->has_patches + 2 * (s->has_alpha != 0) + 4 * (s->has_alpha == 2); }
+
 static float sin_x_over_x_host(float x) {
     if (1 - x * x == 1) return 1;
     return std::sin(x) / x;
@@ -351,7 +358,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
                                  const nnbvh_prim *prims, int n_prims, const float *verts,
                                  int n_verts, const nnbvh_instance *instances, int n_instances,
                                  int device, const nnbvh_animated_transform *animated = nullptr,
-                                 const float *normals = nullptr) {
+                                 const float *normals = nullptr, const float *prim_alpha = nullptr) {
     if (!nodes || !prims || !verts || n_prims <= 0 || n_verts <= 0 || n_instances < 0 ||
         (n_instances > 0 && !instances) || n_top_nodes < 1 || n_top_nodes > n_nodes) {
         set_error("scene_create: null or empty input array");
@@ -397,6 +404,19 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
                           "(nnbvh_scene_create_with_normals)");
                 return nullptr;
             }
+        } else if (is_alpha_patch_kind(p.kind)) {
+            nv = 4;
+            nslots = is_smooth_alpha_patch_kind(p.kind) ? 8 : 4;
+            if (!prim_alpha || (is_smooth_alpha_patch_kind(p.kind) && !normals)) {
+                set_error("scene_create: NNBVH_PRIM_ALPHA_PATCH primitives need the per-primitive alpha array, the "
+                          "smooth ones the vertex normals too (nnbvh_scene_create_with_attributes)");
+                return nullptr;
+            }
+            if (n_instances > 0) {
+                set_error("scene_create: NNBVH_PRIM_ALPHA_PATCH primitives are for single-level scenes "
+                          "(inside two-level scenes they stay NNBVH_PRIM_HOST)");
+                return nullptr;
+            }
         } else if (is_triangle_kind(p.kind)) nv = nslots = 3;
         else if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) nv = nslots = 4;
         else if (p.kind == NNBVH_PRIM_HOST) {
@@ -426,7 +446,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
         return nullptr;
     }
     if (n_instances == 0)
-        return create_scene_device_bake(nodes, n_nodes, prims, n_prims, verts, n_verts, depth, device, normals);
+        return create_scene_device_bake(nodes, n_nodes, prims, n_prims, verts, n_verts, depth, device, normals, prim_alpha);
     // interior record numbers (global over all trees) and node refs
     std::vector<int> ord((size_t)n_nodes, -1);
     int n_interior = 0;
@@ -595,7 +615,7 @@ nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, 
     BakedScene b;
     bool ok = r.depth <= kMaxStack;
     if (!ok) err = "scene_create: tree deeper than the 64-entry traversal stack";
-    ok = ok && bake_on_device(r.d_nodes, r.total_nodes, r.d_ordered, n_prims, r.d_verts, device, &b, &err);
+    ok = ok && bake_on_device(r.d_nodes, r.total_nodes, r.d_ordered, n_prims, r.d_verts, device, &b, &err, nullptr, nullptr);
     for (void *p : {r.d_nodes, r.d_ordered, r.d_verts})
         if (p) (void)hipFree(p);
     if (!ok) {
@@ -612,6 +632,13 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
                                 const nnbvh_prim *prims, int n_prims, const float *verts,
                                 int n_verts, int device) {
     return create_scene(nodes, n_nodes, n_nodes, prims, n_prims, verts, n_verts, nullptr, 0, device);
+}
+
+nnbvh_scene *nnbvh_scene_create_with_attributes(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
+                                                int n_prims, const float *verts, const float *normals,
+                                                const float *prim_alpha, int n_verts, int device) {
+    return create_scene(nodes, n_nodes, n_nodes, prims, n_prims, verts, n_verts, nullptr, 0, device, nullptr, normals,
+                        prim_alpha);
 }
 
 nnbvh_scene *nnbvh_scene_create_with_normals(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
@@ -729,7 +756,7 @@ static int grid_blocks(nnbvh_scene *s, int mode) {
         dummy.anim = s->d_anim;                  // ... and between the static- and the animated-instance ones
         dummy.fits32 = scene_fits32(s);
         int occ = 0;
-        if (launch_trace(mode, dummy, s->window, s->instanced, s->has_patches + 2 * s->has_alpha, 0, nullptr, &occ) != hipSuccess ||
+        if (launch_trace(mode, dummy, s->window, s->instanced, patch_bits(s), 0, nullptr, &occ) != hipSuccess ||
             occ <= 0)
             occ = std::max(1, std::min(8, 160 / (s->window * 2)));
         per_cu = occ;
@@ -892,7 +919,7 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
     int blocks = grid_blocks(s, mode);
     const int64_t need = (n + kBlockThreads - 1) / kBlockThreads;
     if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
-    if (!hip_ok(launch_trace(mode, p, s->window, s->instanced, s->has_patches + 2 * s->has_alpha, blocks, stream, nullptr),
+    if (!hip_ok(launch_trace(mode, p, s->window, s->instanced, patch_bits(s), blocks, stream, nullptr),
                 "trace kernel launch"))
         return NNBVH_ERR_DEVICE;
     return NNBVH_OK;
@@ -1015,7 +1042,7 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
         int blocks = grid_blocks(s, 3);
         const int64_t need = (total + kBlockThreads - 1) / kBlockThreads;
         if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
-        if (!hip_ok(launch_trace(3, p, s->window, s->instanced, s->has_patches + 2 * s->has_alpha, blocks, stream,
+        if (!hip_ok(launch_trace(3, p, s->window, s->instanced, patch_bits(s), blocks, stream,
                                  nullptr), "fused trace kernel launch"))
             return NNBVH_ERR_DEVICE;
         return NNBVH_OK;

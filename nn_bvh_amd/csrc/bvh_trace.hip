@@ -69,6 +69,11 @@ constexpr int kEnter = (int)0x80000002;   // INST = 2: the lane waits to enter a
 #endif
 // INST = 2: weight of a lane waiting to enter an AnimatedPrimitive in the step selection (interior = 16); 0 = enter
 // at once inside the primitive step (the round-2 form: 11 of 64 lanes active in the interpolation)
+// ALPHA = 2 (alpha-tested bilinear patches: the patch's interaction point and normal, the re-trace loop): 150-155
+// VGPRs; at 4 waves 22-27 spilled registers, at 5 52-68
+#ifndef NNBVH_MINW_ALPHA_PATCH
+#define NNBVH_MINW_ALPHA_PATCH 3
+#endif
 #ifndef NNBVH_ANIM_ENTER_WEIGHT
 #define NNBVH_ANIM_ENTER_WEIGHT 8
 #endif
@@ -112,7 +117,7 @@ constexpr int kEnter = (int)0x80000002;   // INST = 2: the lane waits to enter a
 // ALPHA = 1: the scene holds alpha-tested triangles (kPrimAlpha, cpu/primitive.cpp:57-70); compiled
 // separately so that other scenes pay nothing for the hash and the re-trace.
 template <int MODE, int W, int INST, int PATCH, int ALPHA = 0>
-__global__ __launch_bounds__(kBlockThreads, (INST ? 1 : (ALPHA ? NNBVH_MINW_ALPHA : ((MODE == 0 || MODE == 3) ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY) + (PATCH ? 0 : NNBVH_LEAN_EXTRA_WAVES))))
+__global__ __launch_bounds__(kBlockThreads, (INST ? 1 : (ALPHA ? (ALPHA == 2 ? NNBVH_MINW_ALPHA_PATCH : NNBVH_MINW_ALPHA) : ((MODE == 0 || MODE == 3) ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY) + (PATCH ? 0 : NNBVH_LEAN_EXTRA_WAVES))))
 void trace_kernel(TraceParams p) {
     static_assert(PATCH || !INST, "two-level scenes need the ray direction");
     static_assert(PATCH || !ALPHA, "the alpha test hashes the ray direction");
@@ -341,9 +346,55 @@ void trace_kernel(TraceParams p) {
                 x2 = 0.0f;
                 const V3 rd = {cold[PATCH ? kColdD : 0][lane], cold[PATCH ? kColdD + 1 : 0][lane],
                                cold[PATCH ? kColdD + 2 : 0][lane]};
-                hit = patch_test(r, rd, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                 {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
-                next = slot + 4;
+                next = slot + ((ALPHA == 2 && (flags & kPrimSmooth)) ? 8 : 4);
+                if constexpr (ALPHA == 2) {
+                    // GeometricPrimitive::Intersect around a BilinearPatch (cpu/primitive.cpp:50-70).  A non-planar
+                    // patch can be met again by the ray spawned off its own surface, so the recursion of :63-69 is
+                    // followed: level k tests the ray of level k (its origin goes into the hash), up to
+                    // kAlphaPatchDepth re-traces, beyond which the record is void (the caller re-traces the ray)
+                    constexpr int kAlphaPatchDepth = 3;
+                    const float a = (flags & kPrimAlpha) ? s2.w : 1.0f;
+                    RayState rn = r;  // patch_test reads the origin only
+                    float tm = tMax, t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+                    int k = 0;
+                    for (;;) {
+                        hit = patch_test(rn, rd, tm, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z},
+                                         {s3.x, s3.y, s3.z}, x0, x1, th);
+                        if (!hit || !(a < 1)) break;  // :52-54 / :58
+                        const float u = (a <= 0) ? 1.f : hash_float_6f(rn.o, rd);
+                        if (!(u > a)) break;  // accepted: (x0, x1, th) are this level's
+                        if (k == kAlphaPatchDepth) {
+                            hit = false;
+                            cold[kColdHost][lane] = 1.0f;
+                            break;
+                        }
+                        if (k == 0) t0 = th;
+                        else if (k == 1) t1 = th;
+                        else t2 = th;
+                        ++k;
+                        V3 n00 = {0, 0, 0}, n10 = n00, n01 = n00, n11 = n00;
+                        if (flags & kPrimSmooth) {
+                            const float4 m0 = p.prims[slot + 4], m1 = p.prims[slot + 5], m2 = p.prims[slot + 6],
+                                         m3 = p.prims[slot + 7];
+                            n00 = {m0.x, m0.y, m0.z}, n10 = {m1.x, m1.y, m1.z}, n01 = {m2.x, m2.y, m2.z},
+                            n11 = {m3.x, m3.y, m3.z};
+                        }
+                        // rNext = si->intr.SpawnRay(r.d); Intersect(rNext, tMax - si->tHit)
+                        rn.o = patch_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z},
+                                                    {s3.x, s3.y, s3.z}, x0, x1, (flags & kPrimFlipN) != 0, rd,
+                                                    (flags & kPrimSmooth) != 0, n00, n10, n01, n11);
+                        tm = tm - th;
+                        tests += 1;
+                    }
+                    if (hit && k > 0) {  // siNext->tHit += si->tHit (:67-68), unwinding from the deepest level
+                        if (k == 3) th = th + t2;
+                        if (k >= 2) th = th + t1;
+                        th = th + t0;
+                    }
+                } else {
+                    hit = patch_test(r, rd, tMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                     {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
+                }
             }
             bool closestLane = MODE == 0;
             if (MODE == 3 && hit)
@@ -737,6 +788,10 @@ static hipError_t launch_mode(const TraceParams &p, int window, int instanced, i
     // scenes with alpha-tested triangles and two-level scenes: one instance of the kernel each (window 8)
     // INST: 0 single-level, 1 static instances, 2 instances with AnimatedPrimitives among them (the
     // interpolation of the transform costs 60 VGPRs: 160-177 against 98-116, 2 against 3 wavefronts per SIMD)
+    if (patches & 4) {  // alpha-tested bilinear patches: single-level scenes only (scene creation sees to it)
+        if (instanced) return hipErrorInvalidValue;
+        return launch_one<MODE, 8, 0, 1, 2>(p, blocks, stream, occupancy);
+    }
     if (patches & 2) {
         if (!instanced) return launch_one<MODE, 8, 0, 1, 1>(p, blocks, stream, occupancy);
         return p.anim ? launch_one<MODE, 8, 2, 1, 1>(p, blocks, stream, occupancy)

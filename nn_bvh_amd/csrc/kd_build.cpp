@@ -198,7 +198,7 @@ static bool kd_prepare(const nnbvh_prim *prims, int n_prims, const float *verts,
     primBounds->resize((size_t)n_prims);
     for (int i = 0; i < n_prims; ++i) {
         const nnbvh_prim &p = prims[i];
-        const int nv = nnbvh::is_triangle_kind(p.kind) ? 3 : p.kind == NNBVH_PRIM_BILINEAR_PATCH ? 4 : 0;  // kinds 4 / 5: alpha-tested triangles
+        const int nv = nnbvh::is_triangle_kind(p.kind) ? 3 : (p.kind == NNBVH_PRIM_BILINEAR_PATCH || nnbvh::is_alpha_patch_kind(p.kind)) ? 4 : 0;  // kinds 4 / 5: alpha-tested triangles
         KBox b;
         if (p.kind == NNBVH_PRIM_HOST) {
             if (!prim_bounds) {

@@ -583,9 +583,10 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
         float *s = &rec[(size_t)k * 16];
         uint32_t flags = 0;
         std::memcpy(&s[3], &pr.id, 4);
-        if (pr.kind == NNBVH_PRIM_HOST || is_smooth_alpha_kind(pr.kind)) {
-            // (alpha-tested triangles of smooth meshes: their re-trace needs the vertex normals, which the
-            // 4-slot kd primitive record has no room for — inside a kd-tree they are the host's)
+        if (pr.kind == NNBVH_PRIM_HOST || is_smooth_alpha_kind(pr.kind) || is_alpha_patch_kind(pr.kind)) {
+            // (alpha-tested triangles of smooth meshes and alpha-tested patches: their re-trace needs the vertex normals /
+            // the per-primitive alpha, which the 4-slot kd primitive record has no room for — inside a kd-tree they are
+            // the host's)
             flags |= kPrimHost;
             has_host = true;
         } else if (is_triangle_kind(pr.kind) || pr.kind == NNBVH_PRIM_BILINEAR_PATCH) {

@@ -52,6 +52,8 @@ constexpr uint32_t kPrimFlipN = 64u;
 // instance record of an AnimatedPrimitive: the inverse matrix is interpolated per ray from the
 // animation table (anim_math.h) instead of read from slots 2..4
 constexpr uint32_t kPrimAnimated = 128u;
+// alpha-tested bilinear patch (kPrimPatch | kPrimAlpha): slot 2's fourth word holds alpha like a triangle's; with
+// kPrimSmooth four more slots {n00,0} {n10,0} {n01,0} {n11,0} follow the patch's four
 // alpha-tested triangle of a mesh WITH per-vertex shading normals: three more slots {n0,0} {n1,0} {n2,0} follow
 // (the re-trace after a rejected hit offsets along FaceForward(n, ns), shapes.h:939-951)
 constexpr uint32_t kPrimSmooth = 256u;
@@ -62,6 +64,13 @@ inline bool is_triangle_kind(int kind) {
 }
 inline bool is_smooth_alpha_kind(int kind) {
     return kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH || kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED;
+}
+constexpr bool is_alpha_patch_kind(int kind) { return kind >= NNBVH_PRIM_ALPHA_PATCH && kind <= NNBVH_PRIM_ALPHA_PATCH_SMOOTH_FLIPPED; }
+constexpr bool is_smooth_alpha_patch_kind(int kind) {
+    return kind == NNBVH_PRIM_ALPHA_PATCH_SMOOTH || kind == NNBVH_PRIM_ALPHA_PATCH_SMOOTH_FLIPPED;
+}
+constexpr bool is_flipped_alpha_patch_kind(int kind) {
+    return kind == NNBVH_PRIM_ALPHA_PATCH_FLIPPED || kind == NNBVH_PRIM_ALPHA_PATCH_SMOOTH_FLIPPED;
 }
 inline bool is_flat_alpha_kind(int kind) {
     return kind == NNBVH_PRIM_ALPHA_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED;

@@ -144,4 +144,46 @@ DEV V3 alpha_retrace_origin(V3 p0, V3 p1, V3 p2, float b0, float b1, float b2, b
     return offset_ray_origin(lo, hi, n, d);
 }
 
+// ... after an alpha-rejected BILINEAR PATCH hit at (u, v): BilinearPatch::InteractionFromIntersection (shapes.h:
+// 1396-1489) for a mesh without (u, v) coordinates gives
+//   p = Lerp(u, Lerp(v, p00, p01), Lerp(v, p10, p11)), pError = gamma(6) (|p00| + |p01| + |p10| + |p11|)
+//   dpdu = Lerp(v, p10, p11) - Lerp(v, p00, p01), dpdv = Lerp(u, p01, p11) - Lerp(u, p00, p10)
+//   n = Normalize(Cross(dpdu, dpdv)), negated under reverseOrientation ^ transformSwapsHandedness
+// smooth = the mesh has per-vertex normals: ns = Normalize(bilinear interpolation) where that is not zero, and
+// n = FaceForward(n, ns) (SetShadingGeometry, orientationIsAuthoritative = true)
+DEV V3 lerp_v3(float t, V3 a, V3 b) {  // (1 - t) * a + t * b: vecmath.h:410-412
+    const float s = 1 - t;
+    return {s * a.x + t * b.x, s * a.y + t * b.y, s * a.z + t * b.z};
+}
+DEV V3 patch_retrace_origin(V3 p00, V3 p10, V3 p01, V3 p11, float u, float v, bool flip, V3 d, bool smooth, V3 n00,
+                            V3 n10, V3 n01, V3 n11) {
+    const V3 a = lerp_v3(v, p00, p01), b = lerp_v3(v, p10, p11);
+    const V3 ph = lerp_v3(u, a, b);
+    const V3 dpdu = sub(b, a);
+    const V3 dpdv = sub(lerp_v3(u, p01, p11), lerp_v3(u, p00, p10));
+    constexpr float g6 = gamma_f(6);
+    const V3 pe = {g6 * (((__builtin_fabsf(p00.x) + __builtin_fabsf(p01.x)) + __builtin_fabsf(p10.x)) + __builtin_fabsf(p11.x)),
+                   g6 * (((__builtin_fabsf(p00.y) + __builtin_fabsf(p01.y)) + __builtin_fabsf(p10.y)) + __builtin_fabsf(p11.y)),
+                   g6 * (((__builtin_fabsf(p00.z) + __builtin_fabsf(p01.z)) + __builtin_fabsf(p10.z)) + __builtin_fabsf(p11.z))};
+    const V3 lo = {pe.x == 0 ? ph.x : next_down(ph.x + (-pe.x)), pe.y == 0 ? ph.y : next_down(ph.y + (-pe.y)),
+                   pe.z == 0 ? ph.z : next_down(ph.z + (-pe.z))};
+    const V3 hi = {pe.x == 0 ? ph.x : next_up(ph.x + pe.x), pe.y == 0 ? ph.y : next_up(ph.y + pe.y),
+                   pe.z == 0 ? ph.z : next_up(ph.z + pe.z)};
+    const V3 c = cross(dpdu, dpdv);
+    const float len = __builtin_sqrtf(len2(c));
+    V3 n = {c.x / len, c.y / len, c.z / len};
+    if (flip) n = {n.x * -1, n.y * -1, n.z * -1};
+    if (smooth) {
+        const V3 a0 = lerp_v3(v, n00, n01), a1 = lerp_v3(v, n10, n11);
+        V3 ns = lerp_v3(u, a0, a1);
+        const float l2 = len2(ns);
+        if (l2 > 0) {
+            const float l = __builtin_sqrtf(l2);
+            ns = {ns.x / l, ns.y / l, ns.z / l};
+            if (dot_n(n, ns) < 0.f) n = {-n.x, -n.y, -n.z};
+        }
+    }
+    return offset_ray_origin(lo, hi, n, d);
+}
+
 }  // namespace nnbvh

@@ -659,8 +659,62 @@ void orc_offset_ray_origin(const float lo[3], const float hi[3], const float n[3
 static const float *g_vertex_normals = NULL; /* 3 floats per vertex, indexed like verts; kinds 6 / 7 read it */
 void orc_set_vertex_normals(const float *normals) { g_vertex_normals = normals; }
 
+/* prim kinds 8 .. 11: a BILINEAR PATCH behind such a GeometricPrimitive (9 / 11 = flipped orientation, 10 / 11 = the
+ * mesh has per-vertex normals; meshes with (u, v) coordinates are not covered: their geometric normal depends on the
+ * (s, t) reparametrisation, shapes.h:1414-1437).  The constant alpha comes from a per-primitive array
+ * (orc_set_prim_alpha: the patch needs all four v[]).  A non-planar patch CAN be met again by the ray spawned
+ * off its own surface, so the recursion of :63-69 is real here: it is followed for up to ORC_ALPHA_PATCH_DEPTH
+ * re-traces (a doubly ruled quadric meets a line twice at most; a third re-trace that still hits is numerical
+ * self-intersection), beyond which the record is void and the caller re-traces the ray (*host_io = 1).
+ * siNext->tHit += si->tHit (:67-68) unwinds from the deepest level: ((t_k + t_{k-1}) + ...) + t_0. */
+#define ORC_ALPHA_PATCH_DEPTH 3
+static const float *g_prim_alpha = NULL;
+static const orc_prim *g_prim_alpha_base = NULL;
+void orc_set_prim_alpha(const float *alpha) { g_prim_alpha = alpha; }
+int orc_patch_interaction(const float p12[12], const float *uv8, const float *n12, int flip_normal,
+                          const float hit_uv[2], const float wo[3], float time, int face_index, float out[50]);
+
+static int alpha_patch_intersect(const orc_prim *p, const float *verts, const float o[3], const float d[3],
+                                 float tmax, float res[4], int *tests, int *host_io) {
+    const float a = g_prim_alpha ? g_prim_alpha[p - g_prim_alpha_base] : 1.0f;
+    const int smooth = (p->kind == 10 || p->kind == 11) && g_vertex_normals;
+    const int flip = p->kind == 9 || p->kind == 11;
+    float oc[3] = {o[0], o[1], o[2]}, tm = tmax, ts[ORC_ALPHA_PATCH_DEPTH];
+    int k = 0;
+    for (;;) {
+        float r[4];
+        ++*tests;
+        if (!prim_test(p, verts, oc, d, tm, r)) return 0; /* :52-54 at this level: the whole chain returns {} */
+        int rejected = 0;
+        if (a < 1) { /* :58 */
+            const float u = (a <= 0) ? 1.f : orc_hash_float_6f(oc, d); /* :60, the ray of THIS level */
+            rejected = u > a;
+        }
+        if (!rejected) {
+            float total = r[3];
+            for (int j = k - 1; j >= 0; --j) total = total + ts[j]; /* :67-68, innermost first */
+            res[0] = r[0], res[1] = r[1], res[2] = 0.0f, res[3] = total;
+            return 1;
+        }
+        if (k == ORC_ALPHA_PATCH_DEPTH) {
+            *host_io = 1;
+            return 0;
+        }
+        ts[k++] = r[3];
+        float p12[12], n12[12], wo[3] = {-d[0], -d[1], -d[2]}, rec[50], on[3];
+        for (int j = 0; j < 4; ++j) memcpy(p12 + 3 * j, verts + 3 * (size_t)p->v[j], 12);
+        if (smooth)
+            for (int j = 0; j < 4; ++j) memcpy(n12 + 3 * j, g_vertex_normals + 3 * (size_t)p->v[j], 12);
+        orc_patch_interaction(p12, NULL, smooth ? n12 : NULL, flip, r, wo, 0.0f, 0, rec);
+        orc_offset_ray_origin(rec + 38, rec + 41, rec + 11, d, on); /* rNext = si->intr.SpawnRay(r.d) */
+        memcpy(oc, on, 12);
+        tm = tm - r[3]; /* Intersect(rNext, tMax - si->tHit) */
+    }
+}
+
 static int alpha_intersect(const orc_prim *p, const float *verts, const float o[3], const float d[3],
                            float tmax, float res[4], int *tests, int *host_io) {
+    if (p->kind >= 8 && p->kind <= 11) return alpha_patch_intersect(p, verts, o, d, tmax, res, tests, host_io);
     float r[4];
     ++*tests;
     if (!prim_test(p, verts, o, d, tmax, r)) return 0; /* :52-54 */
@@ -730,7 +784,7 @@ static void closest_tree(const orc_node *nodes, const orc_prim *prims, const flo
                         continue;
                     }
                     int primHit;
-                    if (p->kind >= 4 && p->kind <= 7) {
+                    if (p->kind >= 4 && p->kind <= 11) {
                         primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests, host_io);
                     } else {
                         ++tests;
@@ -817,7 +871,7 @@ static int any_tree(const orc_node *nodes, const orc_prim *prims, const float *v
                         continue;
                     }
                     int primHit; /* GeometricPrimitive::IntersectP with alpha = Intersect(...).has_value(), :79-81 */
-                    if (p->kind >= 4 && p->kind <= 7) {
+                    if (p->kind >= 4 && p->kind <= 11) {
                         primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests, host_io);
                     } else {
                         ++tests;
@@ -919,6 +973,7 @@ void orc_intersect_closest(const orc_node *nodes, int n_nodes, const orc_prim *p
                            const float *verts, const orc_ray *rays, int64_t n, orc_hit *hits,
                            int nthreads) {
     (void)n_nodes;
+    g_prim_alpha_base = prims; /* alpha-tested patches index orc_set_prim_alpha's array by position */
     orc_job j;
     memset(&j, 0, sizeof j);
     j.nodes = nodes;
@@ -934,6 +989,7 @@ void orc_intersect_any(const orc_node *nodes, int n_nodes, const orc_prim *prims
                        const float *verts, const orc_ray *rays, int64_t n, uint8_t *occluded,
                        int32_t *nodes_visited, int32_t *prim_tests, int nthreads) {
     (void)n_nodes;
+    g_prim_alpha_base = prims; /* alpha-tested patches index orc_set_prim_alpha's array by position */
     orc_job j;
     memset(&j, 0, sizeof j);
     j.nodes = nodes;
@@ -1719,7 +1775,7 @@ static void kd_one(const orc_kd_node *nodes, const int32_t *prim_indices, const 
                         continue;
                     }
                     int primHit; /* GeometricPrimitive with a constant alpha: cpu/primitive.cpp:57-70, 79-81 */
-                    if (p->kind >= 4 && p->kind <= 7) {
+                    if (p->kind >= 4 && p->kind <= 11) {
                         primHit = alpha_intersect(p, verts, o, d, rayTMax, r, &tests, &host);
                     } else {
                         ++tests;

@@ -54,8 +54,23 @@ def draw_scene(rng):
             normals[rng.random(len(verts)) < 0.05] = 0  # ns falls back to the geometric normal
         prims["kind"] = np.where(tri, kinds, prims["kind"])
         prims["v"][:, 3] = np.where(tri & (kinds != 0), alpha.view(np.int32), prims["v"][:, 3])
-        return verts, prims, normals
-    return verts, prims, None
+        # alpha-tested bilinear patches (kinds 8 .. 11; alpha from the per-primitive array), some of them twisted
+        # hard enough for a ray to cross them twice (the re-trace after a rejected hit then finds the patch again)
+        patch = prims["kind"] == 1
+        prim_alpha = None
+        if patch.any() and rng.random() < 0.7:
+            pk = rng.choice(np.array([1, 8, 9, 10, 11], np.int32), len(prims))
+            prims["kind"] = np.where(patch, pk, prims["kind"])
+            prim_alpha = alpha
+            if normals is None:
+                normals = rng.normal(size=(len(verts), 3)).astype(np.float32)
+                normals[rng.random(len(verts)) < 0.05] = 0
+            if rng.random() < 0.5:
+                verts = verts.copy()
+                corner = prims["v"][patch, 3]
+                verts[corner] += rng.uniform(-1.0, 1.0, size=(len(corner), 3)).astype(np.float32)
+        return verts, prims, normals, prim_alpha
+    return verts, prims, None, None
 
 
 def draw_rays(rng, verts, prims, n):
@@ -199,17 +214,19 @@ def main():
     for it in range(args.iterations):
         seed = args.seed * 100003 + it
         rng = np.random.default_rng(seed)
-        verts, prims, normals = draw_scene(rng)
+        verts, prims, normals, prim_alpha = draw_scene(rng)
         split = str(rng.choice(["sah", "hlbvh", "middle", "equal"]))
         max_prims = int(rng.choice([1, 2, 4, 8]))
         tree = build_tree(prims, verts, max_prims, split)
-        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals)
+        a_ord = None if prim_alpha is None else prim_alpha[tree.ordered_prims["id"]]
+        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals, prim_alpha=a_ord)
         ob.set_vertex_normals(normals)
+        ob.set_prim_alpha(a_ord)
         if rng.random() < 0.3:
             agg.set_option("stack_window", int(rng.choice([4, 16])))
         rays = draw_rays(rng, verts, prims, args.rays)
         bad, exp = compare(agg, tree, verts, rays)
-        if args.kd and normals is None:  # (inside a kd-tree the smooth kinds are host-only primitives)
+        if args.kd and normals is None and prim_alpha is None:  # (inside a kd-tree the smooth kinds and the alpha patches are host-only primitives)
             kbad = compare_kd(verts, prims, rays, max_prims=int(rng.choice([1, 4])))
             if kbad:
                 print(f"KD MISMATCH seed {seed}: {len(kbad)} rays, first {kbad[:5]}", flush=True)

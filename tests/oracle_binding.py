@@ -329,6 +329,15 @@ def set_sin_mode(mode):
 
 
 _normals_keepalive = None
+_alpha_keepalive = None
+
+
+def set_prim_alpha(alpha):
+    """Constant alpha per primitive for prim kinds 8 .. 11 (alpha-tested bilinear patches), indexed like the prims
+    array given to closest() / any_hit(); None = none."""
+    global _alpha_keepalive
+    _alpha_keepalive = None if alpha is None else np.ascontiguousarray(alpha, np.float32)
+    lib().orc_set_prim_alpha(None if alpha is None else _p(_alpha_keepalive))
 
 
 def set_vertex_normals(normals):

@@ -192,3 +192,149 @@ def test_device_smooth_alpha_equals_oracle():
     assert np.array_equal(agg.IntersectP(rays), eo)
     assert ((kinds[np.maximum(exp["prim"], 0)] >= 6) & (exp["prim"] >= 0)).mean() > 0.1
     agg.close()
+
+
+# ---- alpha-tested BILINEAR PATCHES (prim kinds 8 .. 11) ---------------------------------------------------------------
+def alpha_patch_scene(seed=31, n_tris=1500, n_patches=2500):
+    """Triangles (plain / alpha-tested) and strongly twisted bilinear patches — a ray can cross such a patch twice, so
+    the re-trace after a rejected hit does find it again — of all five kinds (1, 8 .. 11), random per-vertex normals
+    (half of them on the other side than the geometric normal, a few zero), one constant alpha per primitive."""
+    rng = np.random.default_rng(seed)
+    verts, prims = ss.random_soup(n_tris, n_patches, seed, extent=6.0, size=1.2)
+    verts = verts.copy()
+    pv = prims["v"][n_tris:]
+    verts[pv[:, 3]] += rng.uniform(-1.5, 1.5, size=(n_patches, 3)).astype(np.float32)  # twist the fourth corner
+    prims = prims.copy()
+    kinds = prims["kind"].copy()
+    kinds[:n_tris] = rng.choice(np.array([0, 4, 5], np.int32), n_tris, p=[0.4, 0.3, 0.3])
+    kinds[n_tris:] = rng.choice(np.array([1, 8, 9, 10, 11], np.int32), n_patches, p=[0.2, 0.2, 0.2, 0.2, 0.2])
+    alpha = rng.choice(np.array([0.0, 0.25, 0.5, 0.9, 1.0, 1.5, -0.5], np.float32), len(prims))
+    prims["kind"] = kinds
+    tri_alpha = (kinds == 4) | (kinds == 5)
+    prims["v"][tri_alpha, 3] = alpha[tri_alpha].view(np.int32)
+    normals = rng.normal(size=(len(verts), 3)).astype(np.float32)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    normals[rng.random(len(verts)) < 0.02] = 0
+    return verts, prims, normals, alpha, kinds
+
+
+def _oracle_alpha_patch(tree, verts, normals, alpha_ordered, rays, nthreads=4):
+    try:
+        ob.set_vertex_normals(normals)
+        ob.set_prim_alpha(alpha_ordered)
+        h = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, nthreads)
+        occ = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, nthreads)
+    finally:
+        ob.set_vertex_normals(None)
+        ob.set_prim_alpha(None)
+    return h, occ
+
+
+def test_oracle_alpha_patch_recursion():
+    verts, prims, normals, alpha, kinds = alpha_patch_scene()
+    tree = build_tree(prims, verts)
+    order = tree.ordered_prims["id"]
+    rays = scene.random_rays(40000, verts.min(0) - 1, verts.max(0) + 1, 7)
+    h, (occ, _, _) = _oracle_alpha_patch(tree, verts, normals, alpha[order], rays)
+    # kinds 8 .. 11 build like patches; with alpha >= 1 everywhere they ARE plain patches
+    plain = prims.copy()
+    plain["kind"] = np.where(kinds >= 8, 1, kinds)
+    tp = build_tree(plain, verts)
+    assert tp.nodes.tobytes() == tree.nodes.tobytes()
+    opaque = np.where(kinds >= 8, np.float32(1.0), alpha)
+    ho, _ = _oracle_alpha_patch(tree, verts, normals, opaque[order], rays)
+    hp = ob.closest(tp.nodes, tp.ordered_prims, verts, rays, 4)
+    assert ho.tobytes() == hp.tobytes()
+    # alpha <= 0: the patch is crossed (every crossing costs a test and a re-trace), never hit
+    clear = np.where(kinds >= 8, np.float32(0.0), alpha)
+    hc, _ = _oracle_alpha_patch(tree, verts, normals, clear[order], rays)
+    hit_kind = kinds[np.maximum(hc["prim"], 0)]
+    assert (hit_kind[hc["prim"] >= 0] < 8).all()
+    # the recursion is real: rays whose FIRST crossing of a mid-alpha patch was rejected and whose SECOND crossing of
+    # the same patch was accepted report that patch at a larger t than the plain scene does
+    mid = (alpha > 0) & (alpha < 1) & (kinds >= 8)
+    same = (h["prim"] >= 0) & (h["prim"] == hp["prim"]) & mid[np.maximum(h["prim"], 0)]
+    second = same & (h["t"] > hp["t"] * 1.0001)
+    assert second.sum() > 20, second.sum()
+    assert (h["prim_tests"][second] > hp["prim_tests"][second]).all()
+    # no void records on ordinary rays (three re-traces are enough for a surface a line meets twice at most)
+    assert (h["instance"] == -1).sum() == 0
+    # any-hit follows Intersect(...).has_value()
+    assert np.array_equal(occ == 1, h["prim"] >= 0)
+    # the normals matter only through the offset direction: flat kinds (8 / 9) never read them
+    flat_only = prims.copy()
+    flat_only["kind"] = np.where(kinds >= 10, kinds - 2, kinds)
+    tf = build_tree(flat_only, verts)
+    hf, _ = _oracle_alpha_patch(tf, verts, None, alpha[order], rays)
+    hf2, _ = _oracle_alpha_patch(tf, verts, normals, alpha[order], rays)
+    assert hf.tobytes() == hf2.tobytes()
+
+
+def test_oracle_alpha_patch_degenerate_rays_terminate():
+    verts, prims, normals, alpha, kinds = alpha_patch_scene(33, 300, 600)
+    tree = build_tree(prims, verts)
+    rng = np.random.default_rng(3)
+    rays = scene.random_rays(6000, verts.min(0) - 1, verts.max(0) + 1, 11)
+    special = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-30], np.float32)
+    for f in ("o", "d"):
+        v = rays[f].copy()
+        m = rng.random(v.shape) < 0.15
+        v[m] = rng.choice(special, int(m.sum()))
+        rays[f] = v
+    h, (occ, _, _) = _oracle_alpha_patch(tree, verts, normals, alpha[tree.ordered_prims["id"]], rays)  # must return
+    assert set(np.unique(h["instance"])) <= {0, -1}
+    void = (h["instance"] == -1) & (h["prim"] < 0)
+    assert (occ[void] == 2).all()
+
+
+@pytest.mark.gpu
+def test_device_alpha_patches_equal_oracle():
+    """NNBVH_PRIM_ALPHA_PATCH[_FLIPPED / _SMOOTH / _SMOOTH_FLIPPED]: records and counters bit-equal to the oracle,
+    including the rays that cross a patch twice (re-trace accepted at the second crossing: accumulated tHit), and the
+    degenerate rays (NaN / inf / zero components)."""
+    from nn_bvh_amd import BVHAggregate
+    from nn_bvh_amd._lib import NNBVHError
+    verts, prims, normals, alpha, kinds = alpha_patch_scene(35, 3000, 5000)
+    tree = build_tree(prims, verts)
+    a_ord = alpha[tree.ordered_prims["id"]]
+    rng = np.random.default_rng(5)
+    rays = np.concatenate([scene.random_rays(80000, verts.min(0) - 1, verts.max(0) + 1, 8),
+                           scene.random_rays(10000, verts.min(0), verts.max(0), 10, tmax=0.6)])
+    weird = scene.random_rays(6000, verts.min(0) - 1, verts.max(0) + 1, 11)
+    special = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-30], np.float32)
+    for f in ("o", "d"):
+        v = weird[f].copy()
+        m = rng.random(v.shape) < 0.15
+        v[m] = rng.choice(special, int(m.sum()))
+        weird[f] = v
+    rays = np.concatenate([rays, weird])
+    with pytest.raises(NNBVHError, match="alpha"):
+        BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals)
+    with pytest.raises(NNBVHError, match="normals"):
+        BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, prim_alpha=a_ord)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals, prim_alpha=a_ord)
+    got = agg.Intersect(rays)
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    exp, (eo, ev, et) = _oracle_alpha_patch(tree, verts, normals, a_ord, rays)
+    n_ord = len(rays) - len(weird)
+    assert got[:n_ord].tobytes() == exp[:n_ord].tobytes()
+    # the degenerate rays: a NaN ray can be accepted with NaN t / barycentrics (shapes.cpp:239-266); x86 and gfx950
+    # differ in the sign of the default NaN, so there a NaN equals a NaN and everything else is held to the bit
+    for f in ("prim", "nodes_visited", "prim_tests", "instance"):
+        assert np.array_equal(got[f], exp[f]), f
+    for f in ("t", "b0", "b1", "b2"):
+        same = (got[f].view(np.uint32) == exp[f].view(np.uint32)) | (np.isnan(got[f]) & np.isnan(exp[f]))
+        assert same.all(), f
+    assert np.array_equal(occ, eo) and np.array_equal(vis, ev) and np.array_equal(tst, et)
+    assert np.array_equal(agg.IntersectP(rays), eo)
+    hit_kind = kinds[np.maximum(exp["prim"], 0)]
+    for k in (8, 9, 10, 11):
+        assert ((hit_kind == k) & (exp["prim"] >= 0)).sum() > 300, k
+    # the twice-crossed patches are in the sample: more tests than the plain scene needs
+    plain = prims.copy()
+    plain["kind"] = np.where(kinds >= 8, 1, kinds)
+    tp = build_tree(plain, verts)
+    hp = ob.closest(tp.nodes, tp.ordered_prims, verts, rays, 4)
+    second = (exp["prim"] >= 0) & (exp["prim"] == hp["prim"]) & (exp["t"] > hp["t"] * 1.0001) & (hit_kind >= 8)
+    assert second.sum() > 20
+    agg.close()

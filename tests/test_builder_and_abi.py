@@ -153,7 +153,7 @@ def test_scene_create_validates_tree_and_fails_loudly_without_gpu(nnbvh_lib):
         bad["pmin"][interior[-1], 1] = value if value is not None else bad["pmax"][interior[-1], 1] + 1
         assert not create(bad) and "min > max" in _lib.last_error()
     badp = tree.ordered_prims.copy()
-    badp["kind"][0] = 9
+    badp["kind"][0] = 99
     assert not create(tree.nodes, badp) and "kind" in _lib.last_error()
     if nnbvh_lib.nnbvh_device_count() == 0:
         assert not create(tree.nodes)

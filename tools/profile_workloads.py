@@ -61,9 +61,18 @@ def main():
     import torch
     import scenes_small as ss
     from nn_bvh_amd import BVHAggregate, build_tree, make_prims, scene
-    if which in ("patches", "alpha"):
+    if which in ("patches", "alpha", "alpha_patch"):
+        normals = prim_alpha = None
         if which == "patches":
             verts, prims = ss.random_soup(400_000, 400_000, 31, extent=60.0, size=0.9)
+        elif which == "alpha_patch":  # the "patches" soup with 70 % of the patches alpha-tested (kinds 8 .. 11)
+            verts, prims = ss.random_soup(400_000, 400_000, 31, extent=60.0, size=0.9)
+            rng = np.random.default_rng(35)
+            prims = prims.copy()
+            pk = rng.choice(np.array([1, 8, 9, 10, 11], np.int32), len(prims), p=[0.3, 0.175, 0.175, 0.175, 0.175])
+            prims["kind"] = np.where(prims["kind"] == 1, pk, prims["kind"])
+            prim_alpha = rng.choice(np.array([0.0, 0.25, 0.5, 0.9, 1.0], np.float32), len(prims))
+            normals = rng.normal(size=(len(verts), 3)).astype(np.float32)
         else:
             verts, prims = ss.random_soup(1_000_000, 0, 32, extent=60.0, size=0.9)
             rng = np.random.default_rng(33)
@@ -73,7 +82,9 @@ def main():
             prims["kind"] = kinds
             prims["v"][:, 3] = np.where(kinds == 0, 0, alpha.view(np.int32))
         tree = build_tree(prims, verts)
-        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts)
+        if prim_alpha is not None:
+            prim_alpha = prim_alpha[tree.ordered_prims["id"]]
+        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals, prim_alpha=prim_alpha)
         rays = scene.random_rays(4_000_000, verts.min(0) - 2, verts.max(0) + 2, 34)
         trace_three(torch, agg, rays, which)
     elif which == "anim":
