@@ -259,7 +259,13 @@ int nnbvh_scene_info(const nnbvh_scene *s, int64_t out[6]);
  * is traced and the one before comes down.  Buffers
  * the caller has pinned (hipHostMalloc, hipHostRegister, nnbvh_host_register) are read and written by the
  * copy engines directly; pageable buffers go through pinned staging.  Results do not depend on the chunking. */
-int nnbvh_host_register(void *ptr, size_t bytes); /* pin a caller buffer (hipHostRegister) */
+/* pin a caller buffer (hipHostRegister).  ptr must be PAGE-ALIGNED (4096) and the buffer should own its pages
+ * (mmap, aligned_alloc / posix_memalign of whole pages): a registration covers whole pages, and pages shared with
+ * other heap objects stay mapped into the GPU's address space on behalf of those neighbours — a later pageable
+ * copy the runtime makes for THEM can then fault on the device (seen in round 3: "write access to a read-only
+ * page" in an unrelated hipMemcpy after malloc'ed arrays had been registered and freed).  Unregister before the
+ * memory is freed.  NNBVH_ERR_ARG for a misaligned pointer. */
+int nnbvh_host_register(void *ptr, size_t bytes);
 int nnbvh_host_unregister(void *ptr);
 int nnbvh_intersect_closest(nnbvh_scene *s, const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits);
 /* nodes_visited / prim_tests may be NULL (then the faster non-counting kernel runs) */

@@ -84,19 +84,30 @@ class HipBVHAggregate {
     // splitMethod: "sah" (default) | "middle" | "equal"; maxPrimsInNode default 4.
     // primBounds: 6 floats (min, max) per primitive, read for NNBVH_PRIM_HOST / NNBVH_PRIM_INSTANCE entries
     // (what Primitive::Bounds() returns for them); may be null when the list holds neither
+    // normals: the meshes' per-vertex normals (3 floats per vertex), read for the smooth alpha-tested kinds;
+    // primAlpha: one constant alpha per entry of `prims`, read for the alpha-tested bilinear patches
     HipBVHAggregate(const std::vector<nnbvh_prim> &prims, const std::vector<float> &verts,
                     int maxPrimsInNode = 4, const std::string &splitMethod = "sah", int device = 0,
-                    const std::vector<float> *primBounds = nullptr) {
+                    const std::vector<float> *primBounds = nullptr, const std::vector<float> *normals = nullptr,
+                    const std::vector<float> *primAlpha = nullptr) {
         int method = splitMethod == "sah"      ? NNBVH_SPLIT_SAH
                      : splitMethod == "middle" ? NNBVH_SPLIT_MIDDLE
                      : splitMethod == "equal"  ? NNBVH_SPLIT_EQUAL_COUNTS
                      : splitMethod == "hlbvh"  ? NNBVH_SPLIT_HLBVH
                                                : -1;
+        // the builder reorders the primitives; with a per-primitive array to carry along, build with the
+        // position as the id and put the caller's ids back afterwards
+        std::vector<nnbvh_prim> tagged;
+        if (primAlpha) {
+            tagged = prims;
+            for (size_t i = 0; i < tagged.size(); ++i) tagged[i].id = (int32_t)i;
+        }
+        const nnbvh_prim *in = primAlpha ? tagged.data() : prims.data();
         nnbvh_build *b = primBounds
-                             ? nnbvh_build_create_with_bounds(prims.data(), (int)prims.size(), verts.data(),
+                             ? nnbvh_build_create_with_bounds(in, (int)prims.size(), verts.data(),
                                                               (int)(verts.size() / 3), primBounds->data(),
                                                               maxPrimsInNode, method)
-                             : nnbvh_build_create(prims.data(), (int)prims.size(), verts.data(),
+                             : nnbvh_build_create(in, (int)prims.size(), verts.data(),
                                                   (int)(verts.size() / 3), maxPrimsInNode, method);
         if (!b) {
             fatal("HipBVHAggregate: build");
@@ -105,16 +116,37 @@ class HipBVHAggregate {
         int nNodes = 0, nPrims = 0;
         const nnbvh_linear_node *nodes = nnbvh_build_nodes(b, &nNodes);
         const nnbvh_prim *ordered = nnbvh_build_ordered_prims(b, &nPrims);
-        scene_ = nnbvh_scene_create(nodes, nNodes, ordered, nPrims, verts.data(),
-                                    (int)(verts.size() / 3), device);
+        std::vector<nnbvh_prim> restored;
+        std::vector<float> alphaOrdered;
+        if (primAlpha) {
+            restored.assign(ordered, ordered + nPrims);
+            alphaOrdered.resize((size_t)nPrims);
+            for (int i = 0; i < nPrims; ++i) {
+                const size_t from = (size_t)restored[(size_t)i].id;
+                alphaOrdered[(size_t)i] = (*primAlpha)[from];
+                restored[(size_t)i].id = prims[from].id;
+            }
+            ordered = restored.data();
+        }
+        scene_ = (normals || primAlpha)
+                     ? nnbvh_scene_create_with_attributes(nodes, nNodes, ordered, nPrims, verts.data(),
+                                                          normals ? normals->data() : nullptr,
+                                                          primAlpha ? alphaOrdered.data() : nullptr,
+                                                          (int)(verts.size() / 3), device)
+                     : nnbvh_scene_create(nodes, nNodes, ordered, nPrims, verts.data(), (int)(verts.size() / 3), device);
         nnbvh_build_destroy(b);
         if (!scene_) fatal("HipBVHAggregate: scene_create");
     }
 
     // from a tree pbrt itself built: BVHAggregate::nodes + the leaf-ordered primitives
+    // (normals as above; primAlpha indexed like orderedPrims)
     HipBVHAggregate(const nnbvh_linear_node *nodes, int nNodes, const nnbvh_prim *orderedPrims,
-                    int nPrims, const float *verts, int nVerts, int device = 0) {
-        scene_ = nnbvh_scene_create(nodes, nNodes, orderedPrims, nPrims, verts, nVerts, device);
+                    int nPrims, const float *verts, int nVerts, int device = 0, const float *normals = nullptr,
+                    const float *primAlpha = nullptr) {
+        scene_ = (normals || primAlpha)
+                     ? nnbvh_scene_create_with_attributes(nodes, nNodes, orderedPrims, nPrims, verts, normals, primAlpha,
+                                                          nVerts, device)
+                     : nnbvh_scene_create(nodes, nNodes, orderedPrims, nPrims, verts, nVerts, device);
         if (!scene_) fatal("HipBVHAggregate: scene_create");
     }
 

@@ -1694,6 +1694,12 @@ int nnbvh_host_register(void *ptr, size_t bytes) {
         set_error("host_register: bad argument");
         return NNBVH_ERR_ARG;
     }
+    if (reinterpret_cast<uintptr_t>(ptr) % 4096 != 0) {
+        // a registration covers whole pages: a buffer that shares its first page with other heap objects would
+        // leave THEIR memory mapped into the GPU's address space (include/nnbvh.h)
+        set_error("host_register: the buffer must be page-aligned (4096) and own its pages");
+        return NNBVH_ERR_ARG;
+    }
     return hip_ok(hipHostRegister(ptr, bytes, hipHostRegisterDefault), "hipHostRegister") ? NNBVH_OK : NNBVH_ERR_DEVICE;
 }
 

@@ -144,6 +144,22 @@ int main() {
         if (batches * 2 > traced) return 32;  // on average more than two rays per launch
         std::printf("coalesced: %llu rays in %llu batches\n", (unsigned long long)traced, (unsigned long long)batches);
     }
+    // an alpha-tested bilinear patch (per-primitive alpha array, reordered with the primitives by the adapter):
+    // opaque it stops the ray, fully transparent it lets the ray through to the triangle behind it
+    {
+        std::vector<float> v = {-1, -1, 0, 1, -1, 0, -1, 1, 0, 1, 1, 0.3f,  // a (slightly twisted) patch in z ~ 0
+                                -1, -1, 2, 1, -1, 2, 0, 1, 2};             // a triangle behind it, z = 2
+        std::vector<nnbvh_prim> pr = {nnbvh_prim{NNBVH_PRIM_TRIANGLE, 70, {4, 5, 6, 0}},
+                                      nnbvh_prim{NNBVH_PRIM_ALPHA_PATCH, 71, {0, 1, 2, 3}}};
+        const nnbvh::Ray down{{0.1f, -0.2f, -3}, {0, 0, 1}, 0};
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<float> alpha = {0.0f, pass == 0 ? 1.0f : 0.0f};
+            nnbvh::HipBVHAggregate a(pr, v, 1, "sah", 0, nullptr, nullptr, &alpha);
+            auto si = a.Intersect(down);
+            if (!si || si->prim != (pass == 0 ? 71 : 70)) return 40 + pass;
+            if (!a.IntersectP(down)) return 42;
+        }
+    }
     // the film: an empty film reads back as zeros (accumulation itself: tests/test_film.py)
     nnbvh::HipFilm film(0, 0, 8, 4);
     std::vector<double> px = film.Read();

@@ -513,9 +513,17 @@ def test_host_buffer_pipeline_is_independent_of_chunking_and_pinning():
     exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, nthreads=8)
     eocc, evis, etst = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, nthreads=8)
     L = _lib.lib()
-    pinned_rays, pinned_hits = rays.copy(), np.zeros(len(rays), exp.dtype)
-    for a in (pinned_rays, pinned_hits):
-        assert L.nnbvh_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes) == 0, _lib.last_error()
+    # buffers to pin own their pages (anonymous mappings): a registration covers whole pages, and heap pages shared
+    # with other arrays must not stay mapped into the GPU's address space (include/nnbvh.h, nnbvh_host_register)
+    import mmap
+    maps = [mmap.mmap(-1, (len(rays) * 32 + 4095) // 4096 * 4096) for _ in range(2)]
+    pinned_rays = np.frombuffer(maps[0], rays.dtype, len(rays))
+    pinned_hits = np.frombuffer(maps[1], exp.dtype, len(rays))
+    pinned_rays[:] = rays
+    assert L.nnbvh_host_register(ctypes.c_void_p(rays.ctypes.data + 32), 4096) != 0 and "page-aligned" in _lib.last_error()
+    for a, m in zip((pinned_rays, pinned_hits), maps):
+        assert a.ctypes.data % 4096 == 0
+        assert L.nnbvh_host_register(ctypes.c_void_p(a.ctypes.data), len(m)) == 0, _lib.last_error()
     try:
         for chunk in (4096, 20000, 1 << 20):
             agg.set_option("host_chunk", chunk)
@@ -529,5 +537,8 @@ def test_host_buffer_pipeline_is_independent_of_chunking_and_pinning():
         assert agg.Intersect(rays[:1]).tobytes() == exp[:1].tobytes() and len(agg.Intersect(rays[:0])) == 0
     finally:
         for a in (pinned_rays, pinned_hits):
-            L.nnbvh_host_unregister(ctypes.c_void_p(a.ctypes.data))
+            assert L.nnbvh_host_unregister(ctypes.c_void_p(a.ctypes.data)) == 0, _lib.last_error()
     agg.close()
+    del pinned_rays, pinned_hits
+    for m in maps:
+        m.close()

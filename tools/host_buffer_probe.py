@@ -50,9 +50,12 @@ def main():
     chunks = lambda c: -(-n // max(c, -(-n // 6)))  # noqa: E731  (at most 6 chunks of at least host_chunk rays)
     rate(f"pageable buffers, {chunks(1 << 20)} chunks", primary, out)
     L = _lib.lib()
-    pr, po = primary.copy(), np.zeros(n, HIT_DTYPE)
-    for a in (pr, po):
-        _lib.check(L.nnbvh_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes), "nnbvh_host_register")
+    import mmap  # buffers to pin own their pages (include/nnbvh.h, nnbvh_host_register)
+    maps = [mmap.mmap(-1, (n * 32 + 4095) // 4096 * 4096) for _ in range(2)]
+    pr, po = np.frombuffer(maps[0], primary.dtype, n), np.frombuffer(maps[1], HIT_DTYPE, n)
+    pr[:] = primary
+    for a, m in zip((pr, po), maps):
+        _lib.check(L.nnbvh_host_register(ctypes.c_void_p(a.ctypes.data), len(m)), "nnbvh_host_register")
     rate(f"pinned buffers (nnbvh_host_register), {chunks(1 << 20)} chunks", pr, po)
     for c in (1 << 22, n // 2 + 1):
         agg.set_option("host_chunk", c)
