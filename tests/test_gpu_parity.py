@@ -539,6 +539,4 @@ def test_host_buffer_pipeline_is_independent_of_chunking_and_pinning():
         for a in (pinned_rays, pinned_hits):
             assert L.nnbvh_host_unregister(ctypes.c_void_p(a.ctypes.data)) == 0, _lib.last_error()
     agg.close()
-    del pinned_rays, pinned_hits
-    for m in maps:
-        m.close()
+    del a, pinned_rays, pinned_hits  # the mappings go away with their last reference
