@@ -234,6 +234,12 @@ void nnbvh_transform_bounds(const float render_from_prim[12], const float in_min
 nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, const float *verts,
                                           int n_verts, const float *prim_bounds,
                                           int max_prims_in_node, int split_method, int device);
+/* ... with the attributes the alpha-tested kinds read (see nnbvh_scene_create_with_attributes below): normals per
+ * vertex, prim_alpha per entry of `prims` (the CALLER's order: it is carried through the build); either may be NULL */
+nnbvh_scene *nnbvh_scene_create_gpu_build_with_attributes(const nnbvh_prim *prims, int n_prims, const float *verts,
+                                                          int n_verts, const float *prim_bounds, const float *normals,
+                                                          const float *prim_alpha, int max_prims_in_node,
+                                                          int split_method, int device);
 /* nnbvh_scene_create with the meshes' per-vertex shading normals (3 floats per vertex, indexed like `verts`;
  * TriangleMesh::n, util/mesh.h:48): read for NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH[_FLIPPED] primitives only, whose
  * three normals are baked into the primitive stream.  normals = NULL is nnbvh_scene_create. */

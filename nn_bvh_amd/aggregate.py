@@ -129,10 +129,11 @@ class BVHAggregate:
 
     @classmethod
     def build_on_device(cls, prims, verts, max_prims_in_node=4, split_method="sah", prim_bounds=None,
-                        device=0):
+                        device=0, normals=None, prim_alpha=None):
         """Tree built AND baked on the GPU (nnbvh_scene_create_gpu_build): the tree never visits the
         host.  Same traversal results as the host-built aggregate; `nodes` / `ordered_prims` are
-        not available on this object."""
+        not available on this object.  normals (per vertex) / prim_alpha (per entry of `prims`, the caller's order):
+        what the smooth alpha-tested kinds and the alpha-tested patches read."""
         if split_method not in ("sah", "hlbvh"):
             raise NNBVHError(f'GPU build supports "sah" and "hlbvh", not "{split_method}"')
         self = cls.__new__(cls)
@@ -145,10 +146,12 @@ class BVHAggregate:
         self.nodes = self.ordered_prims = None
         self.verts = verts
         self.device = int(device)
-        self._h = L.nnbvh_scene_create_gpu_build(ptr(prims), len(prims), ptr(verts), len(verts),
-                                                 ptr(pb) if pb is not None else None,
-                                                 int(max_prims_in_node), SPLIT_METHODS[split_method],
-                                                 self.device)
+        nrm = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(len(verts), 3)
+        pa = None if prim_alpha is None else np.ascontiguousarray(prim_alpha, np.float32).reshape(len(prims))
+        self._h = L.nnbvh_scene_create_gpu_build_with_attributes(
+            ptr(prims), len(prims), ptr(verts), len(verts), ptr(pb) if pb is not None else None,
+            ptr(nrm) if nrm is not None else None, ptr(pa) if pa is not None else None,
+            int(max_prims_in_node), SPLIT_METHODS[split_method], self.device)
         if not self._h:
             raise NNBVHError("nnbvh_scene_create_gpu_build: " + _lib.last_error())
         self._read_info()

@@ -153,6 +153,19 @@ struct Scratch {
     }
 };
 
+// Device-built scenes with a per-primitive attribute: the build ran with ids = positions in the caller's array, so
+// the ordered primitives say where each one came from; gather the attribute and put the caller's ids back.
+__global__ __launch_bounds__(kBk) void k_gather_alpha_restore_ids(nnbvh_prim *__restrict__ ordered, int n,
+                                                                 const float *__restrict__ alphaIn,
+                                                                 const int *__restrict__ callerIds,
+                                                                 float *__restrict__ alphaOut) {
+    const int i = blockIdx.x * kBk + threadIdx.x;
+    if (i >= n) return;
+    const int from = ordered[i].id;
+    alphaOut[i] = alphaIn[from];
+    ordered[i].id = callerIds[from];
+}
+
 }  // namespace
 
 #define BK_CHECK(expr, what)                                                            \
@@ -254,6 +267,34 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
     out->has_host_prims = flags & 1;
     out->has_patches = (flags & 4) ? 1 : 0;
     out->has_alpha = (flags & 32) ? 2 : ((flags & 8) ? 1 : 0);  // 2: alpha-tested PATCHES present (the ALPHA = 2 kernels)
+    return true;
+}
+
+bool gather_prim_alpha_on_device(void *d_ordered, int n_prims, const float *prim_alpha, const int32_t *caller_ids,
+                                 void **d_alpha_out, std::string *error) {
+    void *dIn = nullptr, *dIds = nullptr, *dOut = nullptr;
+    auto fail = [&](const char *what, hipError_t e) {
+        for (void *p : {dIn, dIds, dOut})
+            if (p) (void)hipFree(p);
+        *error = std::string("device bake: ") + what + ": " + hipGetErrorString(e);
+        return false;
+    };
+    const size_t bytes = (size_t)n_prims * 4;
+    hipError_t e = hipMalloc(&dIn, bytes);
+    if (e == hipSuccess) e = hipMalloc(&dIds, bytes);
+    if (e == hipSuccess) e = hipMalloc(&dOut, bytes);
+    if (e != hipSuccess) return fail("hipMalloc(primitive alpha)", e);
+    e = hipMemcpy(dIn, prim_alpha, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dIds, caller_ids, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail("hipMemcpy(primitive alpha)", e);
+    hipLaunchKernelGGL(k_gather_alpha_restore_ids, dim3((n_prims + kBk - 1) / kBk), dim3(kBk), 0, nullptr,
+                       (nnbvh_prim *)d_ordered, n_prims, (const float *)dIn, (const int *)dIds, (float *)dOut);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail("gather", e);
+    (void)hipFree(dIn);
+    (void)hipFree(dIds);
+    *d_alpha_out = dOut;
     return true;
 }
 

@@ -68,4 +68,9 @@ bool bake_on_device(const void *d_nodes, int n_nodes, const void *d_ordered_prim
                     int device, BakedScene *out, std::string *error, const void *d_normals = nullptr,
                     const void *d_prim_alpha = nullptr);
 
+// d_ordered: leaf-ordered nnbvh_prim[n_prims] of a build that ran with ids = positions in the caller's array;
+// gathers prim_alpha into that order (*d_alpha_out, hipMalloc'ed, the caller's to free) and restores caller_ids
+bool gather_prim_alpha_on_device(void *d_ordered, int n_prims, const float *prim_alpha, const int32_t *caller_ids,
+                                 void **d_alpha_out, std::string *error);
+
 }  // namespace nnbvh

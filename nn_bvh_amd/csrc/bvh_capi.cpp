@@ -587,6 +587,28 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
 nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, const float *verts,
                                           int n_verts, const float *prim_bounds,
                                           int max_prims_in_node, int split_method, int device) {
+    return nnbvh_scene_create_gpu_build_with_attributes(prims, n_prims, verts, n_verts, prim_bounds, nullptr, nullptr,
+                                                        max_prims_in_node, split_method, device);
+}
+
+nnbvh_scene *nnbvh_scene_create_gpu_build_with_attributes(const nnbvh_prim *prims_in, int n_prims, const float *verts,
+                                                          int n_verts, const float *prim_bounds, const float *normals,
+                                                          const float *prim_alpha, int max_prims_in_node,
+                                                          int split_method, int device) {
+    const nnbvh_prim *prims = prims_in;
+    // with a per-primitive array to carry along, the build runs with ids = positions; the bake's gather pass puts the
+    // caller's ids back (bvh_bake.hip)
+    std::vector<nnbvh_prim> tagged;
+    std::vector<int32_t> caller_ids;
+    if (prims_in && prim_alpha && n_prims > 0) {
+        tagged.assign(prims_in, prims_in + n_prims);
+        caller_ids.resize((size_t)n_prims);
+        for (int i = 0; i < n_prims; ++i) {
+            caller_ids[(size_t)i] = tagged[(size_t)i].id;
+            tagged[(size_t)i].id = i;
+        }
+        prims = tagged.data();
+    }
     if (!prims || !verts || n_prims <= 0 || n_verts <= 0) {
         set_error("scene_create_gpu_build: empty primitive or vertex array");
         return nullptr;
@@ -615,8 +637,16 @@ nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, 
     BakedScene b;
     bool ok = r.depth <= kMaxStack;
     if (!ok) err = "scene_create: tree deeper than the 64-entry traversal stack";
-    ok = ok && bake_on_device(r.d_nodes, r.total_nodes, r.d_ordered, n_prims, r.d_verts, device, &b, &err, nullptr, nullptr);
-    for (void *p : {r.d_nodes, r.d_ordered, r.d_verts})
+    void *d_normals = nullptr, *d_alpha = nullptr;
+    if (ok && normals) {
+        ok = hip_ok(hipMalloc(&d_normals, (size_t)n_verts * 12), "hipMalloc(normals)") &&
+             hip_ok(hipMemcpy(d_normals, normals, (size_t)n_verts * 12, hipMemcpyHostToDevice), "hipMemcpy(normals)");
+        if (!ok) err = nnbvh_last_error();
+    }
+    if (ok && prim_alpha)
+        ok = gather_prim_alpha_on_device(r.d_ordered, n_prims, prim_alpha, caller_ids.data(), &d_alpha, &err);
+    ok = ok && bake_on_device(r.d_nodes, r.total_nodes, r.d_ordered, n_prims, r.d_verts, device, &b, &err, d_normals, d_alpha);
+    for (void *p : {r.d_nodes, r.d_ordered, r.d_verts, d_normals, d_alpha})
         if (p) (void)hipFree(p);
     if (!ok) {
         set_error(err);

@@ -191,6 +191,9 @@ def test_device_smooth_alpha_equals_oracle():
     assert np.array_equal(occ, eo) and np.array_equal(vis, ev) and np.array_equal(tst, et)
     assert np.array_equal(agg.IntersectP(rays), eo)
     assert ((kinds[np.maximum(exp["prim"], 0)] >= 6) & (exp["prim"] >= 0)).mean() > 0.1
+    dev = BVHAggregate.build_on_device(prims, verts, 4, "sah", normals=normals)
+    assert dev.Intersect(rays).tobytes() == exp.tobytes()
+    dev.close()
     agg.close()
 
 
@@ -316,6 +319,11 @@ def test_device_alpha_patches_equal_oracle():
     got = agg.Intersect(rays)
     occ, vis, tst = agg.IntersectP(rays, counts=True)
     exp, (eo, ev, et) = _oracle_alpha_patch(tree, verts, normals, a_ord, rays)
+    # built on the device: the per-primitive alpha follows the primitives through the build (caller's order in)
+    dev = BVHAggregate.build_on_device(prims, verts, 4, "sah", normals=normals, prim_alpha=alpha)
+    assert dev.Intersect(rays).tobytes() == got.tobytes()
+    assert np.array_equal(dev.IntersectP(rays), occ)
+    dev.close()
     n_ord = len(rays) - len(weird)
     assert got[:n_ord].tobytes() == exp[:n_ord].tobytes()
     # the degenerate rays: a NaN ray can be accepted with NaN t / barycentrics (shapes.cpp:239-266); x86 and gfx950
