@@ -538,7 +538,7 @@ def main():
     # queues with device-side sizes in, index queues and pixel radiance out), one launch per queue as an
     # integrator whose bounce rays depend on the previous hits must issue them.  Reported next to `value`
     # (dependent_step_ms): the headline's one launch per step needs batches that are independent.
-    wavefront_s = wavefront_intr_s = None
+    wavefront_s = wavefront_intr_s = wavefront_per_queue_s = None
     if not args.no_wavefront and kd is None:
         from nn_bvh_amd.wavefront import RayQueue, WavefrontAggregate, WorkQueue
         from nn_bvh_amd._lib import CLOSEST_QUEUES
@@ -553,13 +553,36 @@ def main():
         d_bhits2 = s0["d_bhits"].view(-1, 32)
         d_b2hits2 = s0["d_b2hits"].view(-1, 32)
 
+        def reset_queues():
+            for q in outq.values():
+                q.Reset()
+
         def step_wavefront():
+            # what the wavefront render loop issues (wavefront/integrator.cpp): depth 0's closest-hit pass; then
+            # the shadow rays of depth 0 WITH the closest-hit pass of depth 1 (both come out of depth 0's shading
+            # and neither reads the other's results: one launch); then depth 2's closest-hit pass
+            reset_queues()
+            wf.IntersectClosest(n_primary, q_primary, hits=d_hits2, **outq)
+            reset_queues()
+            wf.IntersectClosestAndShadow(n_bounce, q_bounce, n_shadow, q_shadow, s0["d_Ld"], s0["d_ru"], s0["d_rl"], pix,
+                                         Lw, hits=d_bhits2, **outq)
+            reset_queues()
+            wf.IntersectClosest(n_bounce2, q_bounce2, hits=d_b2hits2, **outq)
+
+        def step_wavefront_one_launch_per_queue():
             for n_q, q_in, h_out in ((n_primary, q_primary, d_hits2), (n_bounce, q_bounce, d_bhits2),
                                      (n_bounce2, q_bounce2, d_b2hits2)):
-                for q in outq.values():
-                    q.Reset()
+                reset_queues()
                 wf.IntersectClosest(n_q, q_in, hits=h_out, **outq)
             wf.IntersectShadow(n_shadow, q_shadow, s0["d_Ld"], s0["d_ru"], s0["d_rl"], pix, Lw)
+
+        step_wavefront_one_launch_per_queue()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_wavefront_one_launch_per_queue()
+        barrier()
+        wavefront_per_queue_s = max_over_ranks(time.perf_counter() - t1)
 
         step_wavefront()
         barrier()
@@ -752,11 +775,14 @@ def main():
                 "value": round(rays_per_step * world * args.steps / wavefront_s / 1e6, 2),
                 "unit": "Mray/s",
                 "ms_per_step": round(wavefront_s / args.steps * 1e3, 4),
-                "how": "the same four batches through nnbvh_wavefront_intersect_closest/_shadow, one launch per "
-                       "queue (what an integrator whose bounce rays depend on the previous hits must issue): SOA "
-                       "queues in, 6 index queues + pixel radiance out, queue resets included; `value` is the one-"
-                       "launch form, which needs independent batches",
+                "how": "the same four batches through the wavefront-queue entry points in the order an integrator "
+                       "whose bounce rays depend on the previous hits can issue them: closest(depth 0); shadow(depth "
+                       "0) + closest(depth 1) in one launch (nnbvh_wavefront_intersect_closest_and_shadow: both "
+                       "queues come out of depth 0's shading); closest(depth 2).  SOA queues in, 6 index queues + "
+                       "pixel radiance out, queue resets included; `value` is the one-launch form, which needs "
+                       "independent batches",
                 "with_surface_interactions_ms_per_step": round(wavefront_intr_s / args.steps * 1e3, 4),
+                "one_launch_per_queue_ms_per_step": round(wavefront_per_queue_s / args.steps * 1e3, 4),
             }
         if film_allgather_ms is not None:
             result["film_allgather_ms"] = round(film_allgather_ms, 3)

@@ -362,6 +362,17 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
                                      const int32_t *d_size, const float *d_Ld, const float *d_r_u,
                                      const float *d_r_l, const int32_t *d_pixel_index, float *d_L,
                                      int64_t n_pixels, uint8_t *d_occluded, void *stream);
+/* IntersectShadow of depth d and IntersectClosest of depth d + 1 in ONE launch (wavefront/integrator.cpp: the
+ * render loop traces the shadow rays of a depth and then the next depth's rays; both queues were filled by the same
+ * shading pass and neither reads what the other writes).  Same results as the two calls; one ramp-up and one drain
+ * of the traversal kernel instead of two.  Scenes the one-launch kernel does not cover (alpha-tested primitives)
+ * and empty sides run the two calls one after the other. */
+int nnbvh_wavefront_intersect_closest_and_shadow(
+    nnbvh_scene *s, int32_t max_rays, const nnbvh_ray_soa *ray_queue, const int32_t *d_size,
+    const uint8_t *d_prim_class, int64_t n_prim_class, void *d_hits, const nnbvh_closest_queues *out,
+    int32_t max_shadow_rays, const nnbvh_ray_soa *shadow_queue, const int32_t *d_shadow_size, const float *d_Ld,
+    const float *d_r_u, const float *d_r_l, const int32_t *d_pixel_index, float *d_L, int64_t n_pixels,
+    uint8_t *d_occluded, void *stream);
 
 /* WavefrontAggregate::IntersectShadowTr (wavefront/aggregate.cpp:70-88 -> TraceTransmittance,
  * wavefront/intersect.h:164-274) for scenes WITHOUT participating media: a shadow ray passes

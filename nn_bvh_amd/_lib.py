@@ -50,7 +50,7 @@ EXPORTS = [
     "nnbvh_intersect_any_device", "nnbvh_scene_set_option", "nnbvh_scene_sched_stats",
     "nnbvh_trace_batches_device", "nnbvh_scene_create_instanced", "nnbvh_transform_bounds",
     "nnbvh_build_create_with_bounds", "nnbvh_wavefront_intersect_closest",
-    "nnbvh_wavefront_intersect_shadow", "nnbvh_build_create_gpu", "nnbvh_build_gpu_timing",
+    "nnbvh_wavefront_intersect_shadow", "nnbvh_wavefront_intersect_closest_and_shadow", "nnbvh_build_create_gpu", "nnbvh_build_gpu_timing",
     "nnbvh_shading_mesh_create", "nnbvh_shading_mesh_destroy", "nnbvh_triangle_interactions_device",
     "nnbvh_triangle_interactions", "nnbvh_scene_create_gpu_build",
     "nnbvh_shading_mesh_set_instances", "nnbvh_shading_mesh_set_instances_animated", "nnbvh_host_register",
@@ -163,6 +163,9 @@ def lib():
     L.nnbvh_wavefront_intersect_closest.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp]
     L.nnbvh_wavefront_intersect_shadow.restype = i32
     L.nnbvh_wavefront_intersect_shadow.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
+    L.nnbvh_wavefront_intersect_closest_and_shadow.restype = i32
+    L.nnbvh_wavefront_intersect_closest_and_shadow.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp,
+                                                               i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
     L.nnbvh_wavefront_record_shadow_device.restype = i32
     L.nnbvh_wavefront_record_shadow_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     L.nnbvh_film_create.restype = vp

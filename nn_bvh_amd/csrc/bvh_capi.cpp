@@ -1007,6 +1007,62 @@ int nnbvh_intersect_any_device(nnbvh_scene *s, const void *d_rays, int64_t n, vo
                   (hipStream_t)stream, w);
 }
 
+// One mode-3 launch over up to kMaxFusedBatches closest-hit / occlusion-only batches (the caller has checked that
+// the scene and the batches allow it).  d_n: nullable array of nullable device-resident batch sizes.
+static int launch_fused_batches(nnbvh_scene *s, Workspace *w, hipStream_t stream, const nnbvh_batch *batches,
+                                int n_batches, const int32_t *const *d_n) {
+    TraceParams p{};
+    p.wide = s->d_wide;
+    p.prims = s->d_prims;
+    std::memcpy(p.rootMin, s->bounds, 12);
+    std::memcpy(p.rootMax, s->bounds + 3, 12);
+    p.rootRef = s->root_ref;
+    p.queue = w->queue;
+    p.nQueues = s->xcd_queues ? kMaxQueues : 1;
+    p.primWeight = s->prim_weight;
+    p.refillWeight = s->refill_weight;
+    p.stats = s->d_stats;
+    p.intRepeat = s->int_repeat;
+    p.primRepeat = s->prim_repeat;
+    p.fits32 = scene_fits32(s);
+    p.primsOff = (unsigned)((const char *)s->d_prims - (const char *)s->d_wide);
+    p.primMin = scene_prim_min(s);
+    p.hasHostPrims = s->has_host_prims;
+    p.spill = w->spill;
+    p.anim = s->d_anim;
+    int64_t total = 0;
+    for (int i = 0; i < n_batches; ++i) {
+        if (batches[i].n == 0) continue;  // empty batches take no slot
+        const int b = p.nBatches++;
+        p.bRays[b] = (const nnbvh_ray *)batches[i].d_rays;
+        p.bOut[b] = batches[i].d_out;
+        p.bN[b] = (long)batches[i].n;
+        p.bNDev[b] = d_n ? d_n[i] : nullptr;
+        if (batches[i].kind == NNBVH_BATCH_ANY) p.anyMask |= 1u << b;
+        total += batches[i].n;
+    }
+    if (p.nBatches == 0) return NNBVH_OK;
+    p.n = (long)total;
+    if (!hip_ok(launch_zero_queue(w->queue, kMaxFusedBatches * kMaxQueues * kQueueStrideWords, stream),
+                "queue reset launch"))
+        return NNBVH_ERR_DEVICE;
+    int blocks = grid_blocks(s, 3);
+    const int64_t need = (total + kBlockThreads - 1) / kBlockThreads;
+    if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
+    if (!hip_ok(launch_trace(3, p, s->window, s->instanced, patch_bits(s), blocks, stream, nullptr),
+                "fused trace kernel launch"))
+        return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
+}
+
+static bool batches_fusable(const nnbvh_scene *s, const nnbvh_batch *batches, int n_batches) {
+    bool fusable = s->fused_batches && n_batches <= kMaxFusedBatches && s->window == 8 && !s->has_alpha;
+    for (int i = 0; fusable && i < n_batches; ++i)
+        fusable = batches[i].n < (1LL << kFusedIndexBits) &&
+                  !(batches[i].kind == NNBVH_BATCH_ANY && (batches[i].d_nodes_visited || batches[i].d_prim_tests));
+    return fusable;
+}
+
 int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n_batches,
                                void *stream_) {
     if (!s || n_batches < 0 || (n_batches > 0 && !batches)) {
@@ -1028,54 +1084,11 @@ int nnbvh_trace_batches_device(nnbvh_scene *s, const nnbvh_batch *batches, int n
     hipStream_t stream = (hipStream_t)stream_;
     // One launch for all batches (mode 3) when they are closest-hit / occlusion-only any-hit batches of
     // fewer than 2^28 rays each: they share one ramp-up and one drain instead of paying one each.
-    bool fusable = s->fused_batches && n_batches <= kMaxFusedBatches && s->window == 8 && !s->has_alpha;
-    for (int i = 0; fusable && i < n_batches; ++i)
-        fusable = batches[i].n < (1LL << kFusedIndexBits) &&
-                  !(batches[i].kind == NNBVH_BATCH_ANY && (batches[i].d_nodes_visited || batches[i].d_prim_tests));
+    const bool fusable = batches_fusable(s, batches, n_batches);
     if (fusable) {
         Workspace *w = workspace_for(s, stream);
         if (!w) return NNBVH_ERR_DEVICE;
-        TraceParams p{};
-        p.wide = s->d_wide;
-        p.prims = s->d_prims;
-        std::memcpy(p.rootMin, s->bounds, 12);
-        std::memcpy(p.rootMax, s->bounds + 3, 12);
-        p.rootRef = s->root_ref;
-        p.queue = w->queue;
-        p.nQueues = s->xcd_queues ? kMaxQueues : 1;
-        p.primWeight = s->prim_weight;
-        p.refillWeight = s->refill_weight;
-        p.stats = s->d_stats;
-        p.intRepeat = s->int_repeat;
-        p.primRepeat = s->prim_repeat;
-        p.fits32 = scene_fits32(s);
-        p.primsOff = (unsigned)((const char *)s->d_prims - (const char *)s->d_wide);
-        p.primMin = scene_prim_min(s);
-            p.hasHostPrims = s->has_host_prims;
-        p.spill = w->spill;
-        p.anim = s->d_anim;
-        int64_t total = 0;
-        for (int i = 0; i < n_batches; ++i) {
-            if (batches[i].n == 0) continue;  // empty batches take no slot
-            const int b = p.nBatches++;
-            p.bRays[b] = (const nnbvh_ray *)batches[i].d_rays;
-            p.bOut[b] = batches[i].d_out;
-            p.bN[b] = (long)batches[i].n;
-            if (batches[i].kind == NNBVH_BATCH_ANY) p.anyMask |= 1u << b;
-            total += batches[i].n;
-        }
-        if (p.nBatches == 0) return NNBVH_OK;
-        p.n = (long)total;
-        if (!hip_ok(launch_zero_queue(w->queue, kMaxFusedBatches * kMaxQueues * kQueueStrideWords, stream),
-                    "queue reset launch"))
-            return NNBVH_ERR_DEVICE;
-        int blocks = grid_blocks(s, 3);
-        const int64_t need = (total + kBlockThreads - 1) / kBlockThreads;
-        if (need < blocks) blocks = (int)std::max<int64_t>(need, 1);
-        if (!hip_ok(launch_trace(3, p, s->window, s->instanced, patch_bits(s), blocks, stream,
-                                 nullptr), "fused trace kernel launch"))
-            return NNBVH_ERR_DEVICE;
-        return NNBVH_OK;
+        return launch_fused_batches(s, w, stream, batches, n_batches, nullptr);
     }
     if (!s->ev_fork) {
         bool ok = hip_ok(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming), "hipEventCreate");
@@ -1190,6 +1203,75 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
     if (rc != NNBVH_OK) return rc;
     if (!hip_ok(launch_wf_record_shadow(occ, cnt, d_Ld, d_r_u, d_r_l, d_pixel_index, d_L, (long)n_pixels,
                                         max_blocks, stream),
+                "shadow record kernel launch"))
+        return NNBVH_ERR_DEVICE;
+    return NNBVH_OK;
+}
+
+// IntersectShadow of one depth and IntersectClosest of the next (wavefront/integrator.cpp: TraceShadowRays(depth),
+// then the next iteration's IntersectClosest): both queues are filled by the shading of the same depth and neither
+// reads what the other writes, so they can share ONE launch (mode 3: one ramp-up and one drain instead of two).
+int nnbvh_wavefront_intersect_closest_and_shadow(
+    nnbvh_scene *s, int32_t max_rays, const nnbvh_ray_soa *ray_queue, const int32_t *d_size,
+    const uint8_t *d_prim_class, int64_t n_prim_class, void *d_hits, const nnbvh_closest_queues *out,
+    int32_t max_shadow_rays, const nnbvh_ray_soa *shadow_queue, const int32_t *d_shadow_size, const float *d_Ld,
+    const float *d_r_u, const float *d_r_l, const int32_t *d_pixel_index, float *d_L, int64_t n_pixels,
+    uint8_t *d_occluded, void *stream_) {
+    // a scene or sizes the one-launch form does not cover, or one side empty: the two calls one after the other
+    nnbvh_batch probe[2] = {{NNBVH_BATCH_CLOSEST, 0, nullptr, max_rays, nullptr, nullptr, nullptr},
+                            {NNBVH_BATCH_ANY, 0, nullptr, max_shadow_rays, nullptr, nullptr, nullptr}};
+    if (!s || max_rays <= 0 || max_shadow_rays <= 0 || !batches_fusable(s, probe, 2)) {
+        int rc = nnbvh_wavefront_intersect_shadow(s, max_shadow_rays, shadow_queue, d_shadow_size, d_Ld, d_r_u, d_r_l,
+                                                  d_pixel_index, d_L, n_pixels, d_occluded, stream_);
+        if (rc != NNBVH_OK) return rc;
+        return nnbvh_wavefront_intersect_closest(s, max_rays, ray_queue, d_size, d_prim_class, n_prim_class, d_hits,
+                                                 out, stream_);
+    }
+    if (!out || !soa_ok(ray_queue) || !d_hits || n_prim_class < 0 || n_pixels < 0 || !soa_ok(shadow_queue) || !d_Ld ||
+        !d_r_u || !d_r_l || !d_pixel_index || !d_L) {
+        set_error("wavefront_intersect_closest_and_shadow: bad argument");
+        return NNBVH_ERR_ARG;
+    }
+    const nnbvh_work_queue *qs[6] = {&out->escaped, &out->hit_area_light, &out->basic_eval_material,
+                                     &out->universal_eval_material, &out->medium_sample, &out->next_ray};
+    for (const nnbvh_work_queue *q : qs)
+        if (q->size && (q->capacity < 0 || (q->capacity > 0 && !q->items))) {
+            set_error("wavefront_intersect_closest_and_shadow: queue with a size counter but no item storage");
+            return NNBVH_ERR_ARG;
+        }
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return NNBVH_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(s->mu);
+    hipStream_t stream = (hipStream_t)stream_;
+    Workspace *w = workspace_for(s, stream);
+    if (!w) return NNBVH_ERR_DEVICE;
+    const size_t closest_bytes = (size_t)max_rays * sizeof(nnbvh_ray);
+    if (!grow(&w->d_in, &w->in_bytes, closest_bytes + (size_t)max_shadow_rays * sizeof(nnbvh_ray),
+              "hipMalloc(wavefront rays)"))
+        return NNBVH_ERR_DEVICE;
+    uint8_t *occ = d_occluded;
+    if (!occ) {
+        if (!grow(&w->d_out, &w->out_bytes, (size_t)max_shadow_rays, "hipMalloc(wavefront occluded)"))
+            return NNBVH_ERR_DEVICE;
+        occ = (uint8_t *)w->d_out;
+    }
+    void *closest_rays = w->d_in, *shadow_rays = (char *)w->d_in + closest_bytes;
+    const WavefrontCount cnt{max_rays, d_size}, scnt{max_shadow_rays, d_shadow_size};
+    const int max_blocks = s->n_cus * 8;
+    if (!hip_ok(launch_wf_gather(*ray_queue, cnt, closest_rays, max_blocks, stream), "gather kernel launch") ||
+        !hip_ok(launch_wf_gather(*shadow_queue, scnt, shadow_rays, max_blocks, stream), "gather kernel launch"))
+        return NNBVH_ERR_DEVICE;
+    // the (longer) closest-hit batch first: the shadow rays fill the lanes its tail leaves idle
+    const nnbvh_batch batches[2] = {{NNBVH_BATCH_CLOSEST, 0, closest_rays, max_rays, d_hits, nullptr, nullptr},
+                                    {NNBVH_BATCH_ANY, 0, shadow_rays, max_shadow_rays, occ, nullptr, nullptr}};
+    const int32_t *sizes[2] = {d_size, d_shadow_size};
+    const int rc = launch_fused_batches(s, w, stream, batches, 2, sizes);
+    if (rc != NNBVH_OK) return rc;
+    if (!hip_ok(launch_wf_enqueue_closest(d_hits, cnt, ray_queue->has_medium, d_prim_class, (long)n_prim_class, *out,
+                                          max_blocks, stream),
+                "enqueue kernel launch") ||
+        !hip_ok(launch_wf_record_shadow(occ, scnt, d_Ld, d_r_u, d_r_l, d_pixel_index, d_L, (long)n_pixels, max_blocks,
+                                        stream),
                 "shadow record kernel launch"))
         return NNBVH_ERR_DEVICE;
     return NNBVH_OK;

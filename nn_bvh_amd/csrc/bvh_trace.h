@@ -47,6 +47,7 @@ struct TraceParams {
     const nnbvh_ray *bRays[kMaxFusedBatches];
     void *bOut[kMaxFusedBatches];
     long bN[kMaxFusedBatches];
+    const int32_t *bNDev[kMaxFusedBatches];  // nullable: device-resident size of batch b, clamped to [0, bN[b]]
 };
 
 // bvh_layout.cpp: re-orders the baked arrays in memory (speed only; see the modes there)

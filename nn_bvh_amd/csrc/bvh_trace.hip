@@ -589,7 +589,13 @@ void trace_kernel(TraceParams p) {
             if (exhausted) break;  // only reached with every lane idle (sR == 0 otherwise)
             long start = 0;
             for (;;) {  // find a queue with work left (own XCD's first, then steal)
-                if (MODE == 3) nRays = p.bN[curBatch];
+                if (MODE == 3) {
+                    nRays = p.bN[curBatch];
+                    if (const int32_t *nd = p.bNDev[curBatch]) {  // wavefront queues: the size lives on the device
+                        const long v = *nd;
+                        nRays = v < 0 ? 0 : (v < nRays ? v : nRays);
+                    }
+                }
                 // p.nQueues is 1 or kMaxQueues = 8: the division of a long is a shift (the scalar unit has
                 // no 64-bit divide; the compiler's expansion was ~250 instructions per refill)
                 static_assert(kMaxQueues == 8, "queue ranges are computed with a shift by 3");

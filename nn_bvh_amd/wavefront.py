@@ -124,6 +124,37 @@ class WavefrontAggregate:
             torch.cuda.current_stream(self.device).cuda_stream),
             "nnbvh_wavefront_intersect_shadow")
 
+    def IntersectClosestAndShadow(self, max_rays, ray_queue, max_shadow_rays, shadow_queue, Ld, r_u, r_l, pixel_index,
+                                  L, escaped=None, hit_area_light=None, basic_eval_material=None,
+                                  universal_eval_material=None, medium_sample=None, next_ray=None, hits=None,
+                                  occluded=None):
+        """IntersectShadow(max_shadow_rays, shadow_queue, ...) of one depth and IntersectClosest(max_rays, ray_queue,
+        ...) of the next in ONE launch of the traversal kernel (both queues come out of the same shading pass and
+        neither reads what the other writes: wavefront/integrator.cpp's render loop).  Same results as the two calls.
+        Returns the hit records."""
+        assert shadow_queue.tmax is not None, "a shadow queue carries tMax per item"
+        for t in (Ld, r_u, r_l, L):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[-1] == 4
+        assert pixel_index.dtype == torch.int32 and pixel_index.is_contiguous()
+        if hits is None:
+            hits = torch.empty((max(int(max_rays), 1), 32), dtype=torch.uint8, device=self.device)
+        qrec = np.zeros(1, _lib.CLOSEST_QUEUES_DTYPE)
+        given = dict(zip(CLOSEST_QUEUES, (escaped, hit_area_light, basic_eval_material,
+                                          universal_eval_material, medium_sample, next_ray)))
+        for name, q in given.items():
+            if q is not None:
+                q._wire(qrec[name][0:1])
+        soa, ssoa = ray_queue._wire(), shadow_queue._wire()
+        pc = self.prim_class
+        check(_lib.lib().nnbvh_wavefront_intersect_closest_and_shadow(
+            self.aggregate._h, int(max_rays), ptr(soa), ray_queue.size.data_ptr(),
+            pc.data_ptr() if pc is not None else None, 0 if pc is None else pc.numel(), hits.data_ptr(), ptr(qrec),
+            int(max_shadow_rays), ptr(ssoa), shadow_queue.size.data_ptr(), Ld.data_ptr(), r_u.data_ptr(),
+            r_l.data_ptr(), pixel_index.data_ptr(), L.data_ptr(), L.shape[0],
+            occluded.data_ptr() if occluded is not None else None,
+            torch.cuda.current_stream(self.device).cuda_stream), "nnbvh_wavefront_intersect_closest_and_shadow")
+        return hits
+
     def IntersectShadowTr(self, max_rays, shadow_queue, shading_mesh, Ld, r_u, r_l, pixel_index, L, state=None):
         """IntersectShadowTr (wavefront/aggregate.cpp:70-88, TraceTransmittance of wavefront/intersect.h:
         164-274) without media: shadow rays pass through interface surfaces (CLASS_INTERFACE) and are

@@ -180,6 +180,56 @@ def test_gpu_intersect_shadow_records_radiance(device_size):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [(None, None), (5000, 3000), (0, 4000), (7001, 0)])
+def test_gpu_closest_and_shadow_in_one_launch(sizes):
+    """nnbvh_wavefront_intersect_closest_and_shadow = IntersectShadow of one depth + IntersectClosest of the next in
+    one launch (device-side queue sizes per batch): hit records, destination queues, occlusion flags and pixel
+    radiance equal to the oracle's — i.e. to the two separate calls — and nothing is written beyond the queue sizes."""
+    import torch
+    from nn_bvh_amd.wavefront import RayQueue, WorkQueue
+    max_rays, max_shadow, n_pixels = 7001, 6000, 9000
+    verts, prims, tree, agg, rays, WavefrontAggregate = _setup(51, max_rays)
+    srays = scene.random_rays(max_shadow, verts.min(0) - 3, verts.max(0) + 3, 77)
+    srays["tmax"] = np.float32(1 - 1e-4)
+    srays["d"] *= np.float32(12.0)
+    nc = max_rays if sizes[0] is None else sizes[0]
+    ns = max_shadow if sizes[1] is None else sizes[1]
+    rng = np.random.default_rng(5)
+    prim_class = rng.choice(np.array([0, 0, 0, 1, 2, 4, 5], np.uint8), len(prims))
+    has_medium = (rng.random(max_rays) < 0.1).astype(np.uint8)
+    Ld, r_u, r_l, px, L = shadow_inputs(max_shadow, n_pixels, 7)
+    dev = torch.device("cuda", 0)
+    rq, sq = RayQueue.from_records(rays, dev), RayQueue.from_records(srays, dev, shadow=True)
+    rq.has_medium = torch.from_numpy(has_medium).to(dev)
+    if sizes[0] is not None:
+        rq.size.fill_(sizes[0])
+    if sizes[1] is not None:
+        sq.size.fill_(sizes[1])
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    wf = WavefrontAggregate(agg, prim_class)
+    queues = {k: WorkQueue(max_rays, dev) for k in QUEUES}
+    hits_t = torch.full((max_rays, 32), 0xAB, dtype=torch.uint8, device=dev)
+    L_t, occ_t = t(L), torch.full((max_shadow,), 9, dtype=torch.uint8, device=dev)
+    wf.IntersectClosestAndShadow(max_rays, rq, max_shadow, sq, t(Ld), t(r_u), t(r_l), t(px), L_t, hits=hits_t,
+                                 occluded=occ_t, **queues)
+    torch.cuda.synchronize()
+    hits = hits_t.cpu().numpy().view(HIT_DTYPE).reshape(-1)
+    exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays[:nc], nthreads=8)
+    assert hits[:nc].tobytes() == exp.tobytes()
+    assert (hits_t[nc:].cpu().numpy() == 0xAB).all(), "hit records beyond the queue size were written"
+    expq = dict(zip(QUEUES, ob.wavefront_enqueue_closest(exp, has_medium[:nc], prim_class)))
+    for k in QUEUES:
+        assert queues[k].Size() == len(expq[k]), k
+        assert np.array_equal(np.sort(queues[k].indices().cpu().numpy()), expq[k]), k
+    eocc, _, _ = ob.any_hit(tree.nodes, tree.ordered_prims, verts, srays[:ns], nthreads=8)
+    assert np.array_equal(occ_t.cpu().numpy()[:ns], eocc)
+    assert (occ_t.cpu().numpy()[ns:] == 9).all(), "occlusion flags beyond the queue size were written"
+    expL = ob.record_shadow(eocc, Ld[:ns], r_u[:ns], r_l[:ns], px[:ns], L)
+    assert np.array_equal(L_t.cpu().numpy().view(np.uint32), expL.view(np.uint32))
+    agg.close()
+
+
+@pytest.mark.gpu
 def test_gpu_wavefront_bad_arguments():
     import ctypes
     verts, prims, tree, agg, rays, _ = _setup(51, 16)
