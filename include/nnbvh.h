@@ -85,13 +85,19 @@ typedef struct nnbvh_linear_node {
                                        nnbvh_scene_create_with_attributes).  A non-planar patch can be met again by the
                                        ray re-traced off its own surface; the recursion of cpu/primitive.cpp:63-69 is
                                        followed for up to three re-traces, beyond which the record is void
-                                       (needs-host).  For patch meshes WITHOUT (u, v) coordinates — with them the
-                                       geometric normal goes through the (s, t) reparametrisation of shapes.h:
-                                       1414-1437 and the primitive stays NNBVH_PRIM_HOST.  BVH scenes, single level */
+                                       (needs-host).  For patch meshes WITHOUT (u, v) coordinates (with them: kinds
+                                       12 .. 15).  BVH scenes, single level */
 #define NNBVH_PRIM_ALPHA_PATCH_FLIPPED 9         /* same, mesh->reverseOrientation ^ transformSwapsHandedness */
 #define NNBVH_PRIM_ALPHA_PATCH_SMOOTH 10         /* ... of a mesh WITH per-vertex normals (BilinearPatchMesh::n as
                                                      the mesh stores them, util/mesh.cpp:216-223) */
 #define NNBVH_PRIM_ALPHA_PATCH_SMOOTH_FLIPPED 11
+#define NNBVH_PRIM_ALPHA_PATCH_UV 12               /* 8 .. 11 for a mesh WITH (u, v) coordinates (BilinearPatchMesh::uv): the
+                                                      interaction's normal is then Normalize(Cross(dpds, dpdt)) of the
+                                                      (s, t) reparametrisation, shapes.h:1414-1437; needs the scene's
+                                                      per-vertex uvs.  kind = 8 + flipped + 2 * smooth + 4 * uv */
+#define NNBVH_PRIM_ALPHA_PATCH_UV_FLIPPED 13
+#define NNBVH_PRIM_ALPHA_PATCH_UV_SMOOTH 14
+#define NNBVH_PRIM_ALPHA_PATCH_UV_SMOOTH_FLIPPED 15
 
 /* One entry of BVHAggregate::primitives: the shape handle flattened to global vertex
  * indices (Triangle{meshIndex,triIndex} -> mesh->vertexIndices[3*tri..], shapes.cpp:326-328). */
@@ -234,24 +240,25 @@ void nnbvh_transform_bounds(const float render_from_prim[12], const float in_min
 nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, const float *verts,
                                           int n_verts, const float *prim_bounds,
                                           int max_prims_in_node, int split_method, int device);
-/* ... with the attributes the alpha-tested kinds read (see nnbvh_scene_create_with_attributes below): normals per
- * vertex, prim_alpha per entry of `prims` (the CALLER's order: it is carried through the build); either may be NULL */
+/* ... with the attributes the alpha-tested kinds read (see nnbvh_scene_create_with_attributes below): normals and
+ * uvs per vertex, prim_alpha per entry of `prims` (the CALLER's order: it is carried through the build); each may be NULL */
 nnbvh_scene *nnbvh_scene_create_gpu_build_with_attributes(const nnbvh_prim *prims, int n_prims, const float *verts,
                                                           int n_verts, const float *prim_bounds, const float *normals,
-                                                          const float *prim_alpha, int max_prims_in_node,
-                                                          int split_method, int device);
+                                                          const float *uvs, const float *prim_alpha,
+                                                          int max_prims_in_node, int split_method, int device);
 /* nnbvh_scene_create with the meshes' per-vertex shading normals (3 floats per vertex, indexed like `verts`;
  * TriangleMesh::n, util/mesh.h:48): read for NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH[_FLIPPED] primitives only, whose
  * three normals are baked into the primitive stream.  normals = NULL is nnbvh_scene_create. */
 nnbvh_scene *nnbvh_scene_create_with_normals(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
                                              int n_prims, const float *verts, const float *normals, int n_verts,
                                              int device);
-/* ... and with a per-primitive constant alpha (n_prims floats, indexed like `prims`): read for the
- * NNBVH_PRIM_ALPHA_PATCH* primitives only (alpha-tested triangles keep theirs in v[3]).  Either array may be NULL
- * when no primitive needs it. */
+/* ... and with the (u, v) coordinates per vertex (2 floats, read for the NNBVH_PRIM_ALPHA_PATCH_UV* primitives) and a
+ * per-primitive constant alpha (n_prims floats, indexed like `prims`): read for the NNBVH_PRIM_ALPHA_PATCH*
+ * primitives only (alpha-tested triangles keep theirs in v[3]).  Any of the three arrays may be NULL when no
+ * primitive needs it. */
 nnbvh_scene *nnbvh_scene_create_with_attributes(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
                                                 int n_prims, const float *verts, const float *normals,
-                                                const float *prim_alpha, int n_verts, int device);
+                                                const float *uvs, const float *prim_alpha, int n_verts, int device);
 void nnbvh_scene_destroy(nnbvh_scene *s);
 int nnbvh_scene_bounds(const nnbvh_scene *s, float out_min_max[6]);
 /* what the baked device layout looks like: [0]=interior records, [1]=prim-stream slots,

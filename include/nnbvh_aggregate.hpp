@@ -85,11 +85,12 @@ class HipBVHAggregate {
     // primBounds: 6 floats (min, max) per primitive, read for NNBVH_PRIM_HOST / NNBVH_PRIM_INSTANCE entries
     // (what Primitive::Bounds() returns for them); may be null when the list holds neither
     // normals: the meshes' per-vertex normals (3 floats per vertex), read for the smooth alpha-tested kinds;
-    // primAlpha: one constant alpha per entry of `prims`, read for the alpha-tested bilinear patches
+    // primAlpha: one constant alpha per entry of `prims`, read for the alpha-tested bilinear patches; uvs: per-vertex
+    // (u, v), read for the alpha-tested patches of meshes with uv
     HipBVHAggregate(const std::vector<nnbvh_prim> &prims, const std::vector<float> &verts,
                     int maxPrimsInNode = 4, const std::string &splitMethod = "sah", int device = 0,
                     const std::vector<float> *primBounds = nullptr, const std::vector<float> *normals = nullptr,
-                    const std::vector<float> *primAlpha = nullptr) {
+                    const std::vector<float> *primAlpha = nullptr, const std::vector<float> *uvs = nullptr) {
         int method = splitMethod == "sah"      ? NNBVH_SPLIT_SAH
                      : splitMethod == "middle" ? NNBVH_SPLIT_MIDDLE
                      : splitMethod == "equal"  ? NNBVH_SPLIT_EQUAL_COUNTS
@@ -128,9 +129,10 @@ class HipBVHAggregate {
             }
             ordered = restored.data();
         }
-        scene_ = (normals || primAlpha)
+        scene_ = (normals || primAlpha || uvs)
                      ? nnbvh_scene_create_with_attributes(nodes, nNodes, ordered, nPrims, verts.data(),
                                                           normals ? normals->data() : nullptr,
+                                                          uvs ? uvs->data() : nullptr,
                                                           primAlpha ? alphaOrdered.data() : nullptr,
                                                           (int)(verts.size() / 3), device)
                      : nnbvh_scene_create(nodes, nNodes, ordered, nPrims, verts.data(), (int)(verts.size() / 3), device);
@@ -142,10 +144,10 @@ class HipBVHAggregate {
     // (normals as above; primAlpha indexed like orderedPrims)
     HipBVHAggregate(const nnbvh_linear_node *nodes, int nNodes, const nnbvh_prim *orderedPrims,
                     int nPrims, const float *verts, int nVerts, int device = 0, const float *normals = nullptr,
-                    const float *primAlpha = nullptr) {
-        scene_ = (normals || primAlpha)
-                     ? nnbvh_scene_create_with_attributes(nodes, nNodes, orderedPrims, nPrims, verts, normals, primAlpha,
-                                                          nVerts, device)
+                    const float *primAlpha = nullptr, const float *uvs = nullptr) {
+        scene_ = (normals || primAlpha || uvs)
+                     ? nnbvh_scene_create_with_attributes(nodes, nNodes, orderedPrims, nPrims, verts, normals, uvs,
+                                                          primAlpha, nVerts, device)
                      : nnbvh_scene_create(nodes, nNodes, orderedPrims, nPrims, verts, nVerts, device);
         if (!scene_) fatal("HipBVHAggregate: scene_create");
     }

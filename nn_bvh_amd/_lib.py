@@ -108,7 +108,7 @@ def lib():
     L.nnbvh_scene_create_with_normals.restype = vp
     L.nnbvh_scene_create_with_normals.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32]
     L.nnbvh_scene_create_with_attributes.restype = vp
-    L.nnbvh_scene_create_with_attributes.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, i32]
+    L.nnbvh_scene_create_with_attributes.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32]
     L.nnbvh_scene_destroy.restype = None
     L.nnbvh_scene_destroy.argtypes = [vp]
     L.nnbvh_scene_bounds.restype = i32
@@ -138,7 +138,7 @@ def lib():
     L.nnbvh_scene_create_gpu_build.restype = vp
     L.nnbvh_scene_create_gpu_build.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32]
     L.nnbvh_scene_create_gpu_build_with_attributes.restype = vp
-    L.nnbvh_scene_create_gpu_build_with_attributes.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32]
+    L.nnbvh_scene_create_gpu_build_with_attributes.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32]
     L.nnbvh_build_create_gpu.restype = vp
     L.nnbvh_build_create_gpu.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32]
     L.nnbvh_build_gpu_timing.restype = i32

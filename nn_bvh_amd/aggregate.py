@@ -117,19 +117,20 @@ class BVHAggregate:
 
     @classmethod
     def from_tree(cls, nodes, ordered_prims, verts, device=0, instances=None, n_top_nodes=None, animated=None,
-                  normals=None, prim_alpha=None):
+                  normals=None, prim_alpha=None, uvs=None):
         """instances (INSTANCE_DTYPE) + n_top_nodes make a two-level scene: nodes[:n_top_nodes] is
         the top-level tree, the child trees follow (see nn_bvh_amd.instancing).  animated
         (ANIMATED_DTYPE, one per instance) turns instances into AnimatedPrimitives.  normals: per-vertex
         shading normals, needed by alpha-tested triangles / patches of smooth meshes (prim kinds 6 / 7, 10 / 11);
-        prim_alpha: one constant alpha per entry of ordered_prims, read for alpha-tested patches (kinds 8 .. 11)."""
+        prim_alpha: one constant alpha per entry of ordered_prims, read for alpha-tested patches (kinds 8 .. 15);
+        uvs: per-vertex (u, v), read for the alpha-tested patches of meshes with uv (kinds 12 .. 15)."""
         self = cls.__new__(cls)
-        self._init(nodes, ordered_prims, verts, device, None, instances, n_top_nodes, animated, normals, prim_alpha)
+        self._init(nodes, ordered_prims, verts, device, None, instances, n_top_nodes, animated, normals, prim_alpha, uvs)
         return self
 
     @classmethod
     def build_on_device(cls, prims, verts, max_prims_in_node=4, split_method="sah", prim_bounds=None,
-                        device=0, normals=None, prim_alpha=None):
+                        device=0, normals=None, prim_alpha=None, uvs=None):
         """Tree built AND baked on the GPU (nnbvh_scene_create_gpu_build): the tree never visits the
         host.  Same traversal results as the host-built aggregate; `nodes` / `ordered_prims` are
         not available on this object.  normals (per vertex) / prim_alpha (per entry of `prims`, the caller's order):
@@ -148,9 +149,11 @@ class BVHAggregate:
         self.device = int(device)
         nrm = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(len(verts), 3)
         pa = None if prim_alpha is None else np.ascontiguousarray(prim_alpha, np.float32).reshape(len(prims))
+        uv = None if uvs is None else np.ascontiguousarray(uvs, np.float32).reshape(len(verts), 2)
         self._h = L.nnbvh_scene_create_gpu_build_with_attributes(
             ptr(prims), len(prims), ptr(verts), len(verts), ptr(pb) if pb is not None else None,
-            ptr(nrm) if nrm is not None else None, ptr(pa) if pa is not None else None,
+            ptr(nrm) if nrm is not None else None, ptr(uv) if uv is not None else None,
+            ptr(pa) if pa is not None else None,
             int(max_prims_in_node), SPLIT_METHODS[split_method], self.device)
         if not self._h:
             raise NNBVHError("nnbvh_scene_create_gpu_build: " + _lib.last_error())
@@ -165,7 +168,7 @@ class BVHAggregate:
                      "grid_blocks": int(info[4]), "stack_window": int(info[5])}
 
     def _init(self, nodes, ordered_prims, verts, device, depth, instances=None, n_top_nodes=None, animated=None,
-              normals=None, prim_alpha=None):
+              normals=None, prim_alpha=None, uvs=None):
         L = _lib.lib()
         self.nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
         self.ordered_prims = np.ascontiguousarray(ordered_prims, PRIM_DTYPE)
@@ -188,12 +191,14 @@ class BVHAggregate:
         elif prim_alpha is not None:
             self.normals = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
             self.prim_alpha = np.ascontiguousarray(prim_alpha, np.float32).reshape(-1)
+            self.uvs = None if uvs is None else np.ascontiguousarray(uvs, np.float32).reshape(-1, 2)
             assert len(self.prim_alpha) == len(self.ordered_prims)
             assert self.normals is None or len(self.normals) == len(self.verts)
+            assert self.uvs is None or len(self.uvs) == len(self.verts)
             self._h = L.nnbvh_scene_create_with_attributes(
                 ptr(self.nodes), len(self.nodes), ptr(self.ordered_prims), len(self.ordered_prims), ptr(self.verts),
-                ptr(self.normals) if self.normals is not None else None, ptr(self.prim_alpha), len(self.verts),
-                self.device)
+                ptr(self.normals) if self.normals is not None else None,
+                ptr(self.uvs) if self.uvs is not None else None, ptr(self.prim_alpha), len(self.verts), self.device)
         elif normals is not None:
             self.normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
             assert len(self.normals) == len(self.verts)

@@ -37,8 +37,8 @@ __global__ __launch_bounds__(kBk) void k_bake_slot_counts(const nnbvh_prim *__re
         atomicOr(flags, 8 | 16);
     }
     else if (is_alpha_patch_kind(kind)) {
-        c = is_smooth_alpha_patch_kind(kind) ? 8 : 4;  // four slots of vertex normals follow the patch's
-        atomicOr(flags, 4 | 8 | 32 | (is_smooth_alpha_patch_kind(kind) ? 16 : 0));
+        c = alpha_patch_slots(kind);  // four slots of vertex normals and / or two of (u, v) follow the patch's
+        atomicOr(flags, 4 | 8 | 32 | (is_smooth_alpha_patch_kind(kind) ? 16 : 0) | (is_uv_alpha_patch_kind(kind) ? 64 : 0));
     }
     else if (kind != NNBVH_PRIM_TRIANGLE) atomicOr(flags, 2);  // instances are not baked here
     slots[i] = c;
@@ -65,6 +65,7 @@ __device__ __forceinline__ float bake_dop(float a, float b, float c, float d) {
 __global__ __launch_bounds__(kBk) void k_bake_stream(const nnbvh_prim *__restrict__ prims, int n,
                                                     const float *__restrict__ verts,
                                                     const float *__restrict__ normals,
+                                                    const float *__restrict__ uvs,
                                                     const float *__restrict__ primAlpha,
                                                     const int *__restrict__ slotOf,
                                                     const unsigned char *__restrict__ leafLast,
@@ -111,6 +112,12 @@ __global__ __launch_bounds__(kBk) void k_bake_stream(const nnbvh_prim *__restric
             flags |= kPrimSmooth;
             for (int j = 0; j < 4; ++j)
                 s[4 + j] = make_float4(normals[3 * (long)p.v[j]], normals[3 * (long)p.v[j] + 1], normals[3 * (long)p.v[j] + 2], 0);
+        }
+        if (is_uv_alpha_patch_kind(p.kind)) {
+            flags |= kPrimUV;
+            float4 *u = s + (is_smooth_alpha_patch_kind(p.kind) ? 8 : 4);
+            u[0] = make_float4(uvs[2 * (long)p.v[0]], uvs[2 * (long)p.v[0] + 1], uvs[2 * (long)p.v[1]], uvs[2 * (long)p.v[1] + 1]);
+            u[1] = make_float4(uvs[2 * (long)p.v[2]], uvs[2 * (long)p.v[2] + 1], uvs[2 * (long)p.v[3]], uvs[2 * (long)p.v[3] + 1]);
         }
     }
     s[0] = make_float4(v[0][0], v[0][1], v[0][2], __int_as_float(p.id));
@@ -178,7 +185,8 @@ __global__ __launch_bounds__(kBk) void k_gather_alpha_restore_ids(nnbvh_prim *__
     } while (0)
 
 bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int n_prims, const void *d_verts_,
-                    int device, BakedScene *out, std::string *error, const void *d_normals_, const void *d_prim_alpha_) {
+                    int device, BakedScene *out, std::string *error, const void *d_normals_, const void *d_prim_alpha_,
+                    const void *d_uvs_) {
     const auto *dNodes = (const nnbvh_linear_node *)d_nodes_;
     const auto *dPrims = (const nnbvh_prim *)d_prims_;
     const auto *dVerts = (const float *)d_verts_;
@@ -232,6 +240,11 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
                  "(nnbvh_scene_create_with_attributes)";
         return false;
     }
+    if ((flags & 64) && !d_uvs_) {
+        *error = "scene_create: NNBVH_PRIM_ALPHA_PATCH_UV primitives need the per-vertex (u, v) array "
+                 "(nnbvh_scene_create_with_attributes)";
+        return false;
+    }
     if (nSlots <= 0 || nSlots >= 0x7ffffffe) {
         *error = "device bake: primitive stream exceeds 2^31 slots";
         return false;
@@ -244,7 +257,7 @@ bool bake_on_device(const void *d_nodes_, int n_nodes, const void *d_prims_, int
     BK_CHECK(hipMalloc(&dWide, wideBytes + (size_t)nSlots * 16 + 64), "hipMalloc(nodes + primitives)");
     dStream = (char *)dWide + wideBytes;
     BK_CHECK(hipMemsetAsync((char *)dStream + (size_t)nSlots * 16, 0, 64, stream), "memset");
-    hipLaunchKernelGGL(k_bake_stream, dim3(gp), dim3(kBk), 0, stream, dPrims, n_prims, dVerts, (const float *)d_normals_, (const float *)d_prim_alpha_, dSlotOf, dLeafLast,
+    hipLaunchKernelGGL(k_bake_stream, dim3(gp), dim3(kBk), 0, stream, dPrims, n_prims, dVerts, (const float *)d_normals_, (const float *)d_uvs_, (const float *)d_prim_alpha_, dSlotOf, dLeafLast,
                        (float4 *)dStream);
     hipLaunchKernelGGL(k_bake_wide, dim3(gn), dim3(kBk), 0, stream, dNodes, n_nodes, dOrd, dSlotOf, (float4 *)dWide);
     int rootSlot = 0;

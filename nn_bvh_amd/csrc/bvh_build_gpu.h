@@ -66,7 +66,7 @@ struct BakedScene {
 // NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH primitives only
 bool bake_on_device(const void *d_nodes, int n_nodes, const void *d_ordered_prims, int n_prims, const void *d_verts,
                     int device, BakedScene *out, std::string *error, const void *d_normals = nullptr,
-                    const void *d_prim_alpha = nullptr);
+                    const void *d_prim_alpha = nullptr, const void *d_uvs = nullptr);
 
 // d_ordered: leaf-ordered nnbvh_prim[n_prims] of a build that ran with ids = positions in the caller's array;
 // gathers prim_alpha into that order (*d_alpha_out, hipMalloc'ed, the caller's to free) and restores caller_ids

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kB) void k_prim_bounds(const nnbvh_prim *__restrict
         const nnbvh_prim p = prims[i];
         Box6 b;
         box_init(b);
-        const int nv = (p.kind == NNBVH_PRIM_TRIANGLE || (p.kind >= NNBVH_PRIM_ALPHA_TRIANGLE && p.kind <= NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED)) ? 3 : ((p.kind == NNBVH_PRIM_BILINEAR_PATCH || (p.kind >= NNBVH_PRIM_ALPHA_PATCH && p.kind <= NNBVH_PRIM_ALPHA_PATCH_SMOOTH_FLIPPED)) ? 4 : 0);
+        const int nv = (p.kind == NNBVH_PRIM_TRIANGLE || (p.kind >= NNBVH_PRIM_ALPHA_TRIANGLE && p.kind <= NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED)) ? 3 : ((p.kind == NNBVH_PRIM_BILINEAR_PATCH || (p.kind >= NNBVH_PRIM_ALPHA_PATCH && p.kind <= NNBVH_PRIM_ALPHA_PATCH_UV_SMOOTH_FLIPPED)) ? 4 : 0);
         if (p.kind == NNBVH_PRIM_INSTANCE || p.kind == NNBVH_PRIM_HOST) {
             if (!callerBounds) {
                 *err = kErrNeedBounds;

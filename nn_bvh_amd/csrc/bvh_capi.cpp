@@ -299,7 +299,7 @@ static nnbvh_scene *scene_from_baked(const BakedScene &b, int depth, int device)
 // and primitive).
 static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
                                              int n_prims, const float *verts, int n_verts, int depth, int device,
-                                             const float *normals, const float *prim_alpha) {
+                                             const float *normals, const float *prim_alpha, const float *uvs) {
     int n_dev = nnbvh_device_count();
     if (n_dev <= 0 || device < 0 || device >= n_dev) {
         set_error("scene_create: no usable HIP device (this library has no CPU fallback)");
@@ -307,7 +307,8 @@ static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int
     }
     DeviceGuard guard(device);
     if (!guard.ok) return nullptr;
-    void *d_nodes = nullptr, *d_prims = nullptr, *d_verts = nullptr, *d_normals = nullptr, *d_alpha = nullptr;
+    void *d_nodes = nullptr, *d_prims = nullptr, *d_verts = nullptr, *d_normals = nullptr, *d_alpha = nullptr,
+         *d_uvs = nullptr;
     const size_t nb = (size_t)n_nodes * sizeof(nnbvh_linear_node), pbytes = (size_t)n_prims * sizeof(nnbvh_prim),
                  vb = (size_t)n_verts * 12;
     BakedScene b;
@@ -323,11 +324,14 @@ static nnbvh_scene *create_scene_device_bake(const nnbvh_linear_node *nodes, int
     if (ok && prim_alpha)
         ok = hip_ok(hipMalloc(&d_alpha, (size_t)n_prims * 4), "hipMalloc(primitive alpha)") &&
              hip_ok(hipMemcpy(d_alpha, prim_alpha, (size_t)n_prims * 4, hipMemcpyHostToDevice), "hipMemcpy(primitive alpha)");
-    if (ok && !bake_on_device(d_nodes, n_nodes, d_prims, n_prims, d_verts, device, &b, &err, d_normals, d_alpha)) {
+    if (ok && uvs)
+        ok = hip_ok(hipMalloc(&d_uvs, (size_t)n_verts * 8), "hipMalloc(uvs)") &&
+             hip_ok(hipMemcpy(d_uvs, uvs, (size_t)n_verts * 8, hipMemcpyHostToDevice), "hipMemcpy(uvs)");
+    if (ok && !bake_on_device(d_nodes, n_nodes, d_prims, n_prims, d_verts, device, &b, &err, d_normals, d_alpha, d_uvs)) {
         set_error(err);
         ok = false;
     }
-    for (void *p : {d_nodes, d_prims, d_verts, d_normals, d_alpha})
+    for (void *p : {d_nodes, d_prims, d_verts, d_normals, d_alpha, d_uvs})
         if (p) (void)hipFree(p);
     return ok ? scene_from_baked(b, depth, device) : nullptr;
 }
@@ -358,7 +362,8 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
                                  const nnbvh_prim *prims, int n_prims, const float *verts,
                                  int n_verts, const nnbvh_instance *instances, int n_instances,
                                  int device, const nnbvh_animated_transform *animated = nullptr,
-                                 const float *normals = nullptr, const float *prim_alpha = nullptr) {
+                                 const float *normals = nullptr, const float *prim_alpha = nullptr,
+                                 const float *uvs = nullptr) {
     if (!nodes || !prims || !verts || n_prims <= 0 || n_verts <= 0 || n_instances < 0 ||
         (n_instances > 0 && !instances) || n_top_nodes < 1 || n_top_nodes > n_nodes) {
         set_error("scene_create: null or empty input array");
@@ -406,10 +411,11 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
             }
         } else if (is_alpha_patch_kind(p.kind)) {
             nv = 4;
-            nslots = is_smooth_alpha_patch_kind(p.kind) ? 8 : 4;
-            if (!prim_alpha || (is_smooth_alpha_patch_kind(p.kind) && !normals)) {
+            nslots = alpha_patch_slots(p.kind);
+            if (!prim_alpha || (is_smooth_alpha_patch_kind(p.kind) && !normals) || (is_uv_alpha_patch_kind(p.kind) && !uvs)) {
                 set_error("scene_create: NNBVH_PRIM_ALPHA_PATCH primitives need the per-primitive alpha array, the "
-                          "smooth ones the vertex normals too (nnbvh_scene_create_with_attributes)");
+                          "smooth ones the vertex normals, the _UV ones the vertex uvs too "
+                          "(nnbvh_scene_create_with_attributes)");
                 return nullptr;
             }
             if (n_instances > 0) {
@@ -446,7 +452,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
         return nullptr;
     }
     if (n_instances == 0)
-        return create_scene_device_bake(nodes, n_nodes, prims, n_prims, verts, n_verts, depth, device, normals, prim_alpha);
+        return create_scene_device_bake(nodes, n_nodes, prims, n_prims, verts, n_verts, depth, device, normals, prim_alpha, uvs);
     // interior record numbers (global over all trees) and node refs
     std::vector<int> ord((size_t)n_nodes, -1);
     int n_interior = 0;
@@ -588,13 +594,13 @@ nnbvh_scene *nnbvh_scene_create_gpu_build(const nnbvh_prim *prims, int n_prims, 
                                           int n_verts, const float *prim_bounds,
                                           int max_prims_in_node, int split_method, int device) {
     return nnbvh_scene_create_gpu_build_with_attributes(prims, n_prims, verts, n_verts, prim_bounds, nullptr, nullptr,
-                                                        max_prims_in_node, split_method, device);
+                                                        nullptr, max_prims_in_node, split_method, device);
 }
 
 nnbvh_scene *nnbvh_scene_create_gpu_build_with_attributes(const nnbvh_prim *prims_in, int n_prims, const float *verts,
                                                           int n_verts, const float *prim_bounds, const float *normals,
-                                                          const float *prim_alpha, int max_prims_in_node,
-                                                          int split_method, int device) {
+                                                          const float *uvs, const float *prim_alpha,
+                                                          int max_prims_in_node, int split_method, int device) {
     const nnbvh_prim *prims = prims_in;
     // with a per-primitive array to carry along, the build runs with ids = positions; the bake's gather pass puts the
     // caller's ids back (bvh_bake.hip)
@@ -637,7 +643,12 @@ nnbvh_scene *nnbvh_scene_create_gpu_build_with_attributes(const nnbvh_prim *prim
     BakedScene b;
     bool ok = r.depth <= kMaxStack;
     if (!ok) err = "scene_create: tree deeper than the 64-entry traversal stack";
-    void *d_normals = nullptr, *d_alpha = nullptr;
+    void *d_normals = nullptr, *d_alpha = nullptr, *d_uvs = nullptr;
+    if (ok && uvs) {
+        ok = hip_ok(hipMalloc(&d_uvs, (size_t)n_verts * 8), "hipMalloc(uvs)") &&
+             hip_ok(hipMemcpy(d_uvs, uvs, (size_t)n_verts * 8, hipMemcpyHostToDevice), "hipMemcpy(uvs)");
+        if (!ok) err = nnbvh_last_error();
+    }
     if (ok && normals) {
         ok = hip_ok(hipMalloc(&d_normals, (size_t)n_verts * 12), "hipMalloc(normals)") &&
              hip_ok(hipMemcpy(d_normals, normals, (size_t)n_verts * 12, hipMemcpyHostToDevice), "hipMemcpy(normals)");
@@ -645,8 +656,9 @@ nnbvh_scene *nnbvh_scene_create_gpu_build_with_attributes(const nnbvh_prim *prim
     }
     if (ok && prim_alpha)
         ok = gather_prim_alpha_on_device(r.d_ordered, n_prims, prim_alpha, caller_ids.data(), &d_alpha, &err);
-    ok = ok && bake_on_device(r.d_nodes, r.total_nodes, r.d_ordered, n_prims, r.d_verts, device, &b, &err, d_normals, d_alpha);
-    for (void *p : {r.d_nodes, r.d_ordered, r.d_verts, d_normals, d_alpha})
+    ok = ok && bake_on_device(r.d_nodes, r.total_nodes, r.d_ordered, n_prims, r.d_verts, device, &b, &err, d_normals, d_alpha,
+                              d_uvs);
+    for (void *p : {r.d_nodes, r.d_ordered, r.d_verts, d_normals, d_alpha, d_uvs})
         if (p) (void)hipFree(p);
     if (!ok) {
         set_error(err);
@@ -666,9 +678,9 @@ nnbvh_scene *nnbvh_scene_create(const nnbvh_linear_node *nodes, int n_nodes,
 
 nnbvh_scene *nnbvh_scene_create_with_attributes(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,
                                                 int n_prims, const float *verts, const float *normals,
-                                                const float *prim_alpha, int n_verts, int device) {
+                                                const float *uvs, const float *prim_alpha, int n_verts, int device) {
     return create_scene(nodes, n_nodes, n_nodes, prims, n_prims, verts, n_verts, nullptr, 0, device, nullptr, normals,
-                        prim_alpha);
+                        prim_alpha, uvs);
 }
 
 nnbvh_scene *nnbvh_scene_create_with_normals(const nnbvh_linear_node *nodes, int n_nodes, const nnbvh_prim *prims,

@@ -69,8 +69,9 @@ constexpr int kEnter = (int)0x80000002;   // INST = 2: the lane waits to enter a
 #endif
 // INST = 2: weight of a lane waiting to enter an AnimatedPrimitive in the step selection (interior = 16); 0 = enter
 // at once inside the primitive step (the round-2 form: 11 of 64 lanes active in the interpolation)
-// ALPHA = 2 (alpha-tested bilinear patches: the patch's interaction point and normal, the re-trace loop): 150-155
-// VGPRs; at 4 waves 22-27 spilled registers, at 5 52-68
+// ALPHA = 2 (alpha-tested bilinear patches: the patch's interaction point and normal incl. the (s, t)
+// reparametrisation, the re-trace loop): 3 waves = 168 VGPRs with 9-14 spilled; 2 waves (no spills) measured 30 %
+// slower, 4 waves (more spills) no faster
 #ifndef NNBVH_MINW_ALPHA_PATCH
 #define NNBVH_MINW_ALPHA_PATCH 3
 #endif
@@ -346,7 +347,7 @@ void trace_kernel(TraceParams p) {
                 x2 = 0.0f;
                 const V3 rd = {cold[PATCH ? kColdD : 0][lane], cold[PATCH ? kColdD + 1 : 0][lane],
                                cold[PATCH ? kColdD + 2 : 0][lane]};
-                next = slot + ((ALPHA == 2 && (flags & kPrimSmooth)) ? 8 : 4);
+                next = slot + 4 + ((ALPHA == 2 && (flags & kPrimSmooth)) ? 4 : 0) + ((ALPHA == 2 && (flags & kPrimUV)) ? 2 : 0);
                 if constexpr (ALPHA == 2) {
                     // GeometricPrimitive::Intersect around a BilinearPatch (cpu/primitive.cpp:50-70).  A non-planar
                     // patch can be met again by the ray spawned off its own surface, so the recursion of :63-69 is
@@ -379,10 +380,17 @@ void trace_kernel(TraceParams p) {
                             n00 = {m0.x, m0.y, m0.z}, n10 = {m1.x, m1.y, m1.z}, n01 = {m2.x, m2.y, m2.z},
                             n11 = {m3.x, m3.y, m3.z};
                         }
+                        float4 uvA = {0, 0, 0, 0}, uvB = uvA;  // {uv00, uv10} {uv01, uv11}
+                        if (flags & kPrimUV) {
+                            const int at = slot + 4 + ((flags & kPrimSmooth) ? 4 : 0);
+                            uvA = p.prims[at];
+                            uvB = p.prims[at + 1];
+                        }
                         // rNext = si->intr.SpawnRay(r.d); Intersect(rNext, tMax - si->tHit)
                         rn.o = patch_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z},
                                                     {s3.x, s3.y, s3.z}, x0, x1, (flags & kPrimFlipN) != 0, rd,
-                                                    (flags & kPrimSmooth) != 0, n00, n10, n01, n11);
+                                                    (flags & kPrimSmooth) != 0, n00, n10, n01, n11,
+                                                    (flags & kPrimUV) != 0, uvA, uvB);
                         tm = tm - th;
                         tests += 1;
                     }

@@ -53,10 +53,12 @@ constexpr uint32_t kPrimFlipN = 64u;
 // animation table (anim_math.h) instead of read from slots 2..4
 constexpr uint32_t kPrimAnimated = 128u;
 // alpha-tested bilinear patch (kPrimPatch | kPrimAlpha): slot 2's fourth word holds alpha like a triangle's; with
-// kPrimSmooth four more slots {n00,0} {n10,0} {n01,0} {n11,0} follow the patch's four
+// kPrimSmooth four more slots {n00,0} {n10,0} {n01,0} {n11,0} follow the patch's four; with kPrimUV two more,
+// {uv00, uv10} {uv01, uv11}, after those
 // alpha-tested triangle of a mesh WITH per-vertex shading normals: three more slots {n0,0} {n1,0} {n2,0} follow
 // (the re-trace after a rejected hit offsets along FaceForward(n, ns), shapes.h:939-951)
 constexpr uint32_t kPrimSmooth = 256u;
+constexpr uint32_t kPrimUV = 512u;  // alpha-tested patch of a mesh with (u, v) coordinates
 constexpr int kAnimStride = 76;  // floats per entry of the animation table (layout: anim_math.h)
 inline bool is_triangle_kind(int kind) {
     return kind == NNBVH_PRIM_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED ||
@@ -65,13 +67,12 @@ inline bool is_triangle_kind(int kind) {
 inline bool is_smooth_alpha_kind(int kind) {
     return kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH || kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED;
 }
-constexpr bool is_alpha_patch_kind(int kind) { return kind >= NNBVH_PRIM_ALPHA_PATCH && kind <= NNBVH_PRIM_ALPHA_PATCH_SMOOTH_FLIPPED; }
-constexpr bool is_smooth_alpha_patch_kind(int kind) {
-    return kind == NNBVH_PRIM_ALPHA_PATCH_SMOOTH || kind == NNBVH_PRIM_ALPHA_PATCH_SMOOTH_FLIPPED;
-}
-constexpr bool is_flipped_alpha_patch_kind(int kind) {
-    return kind == NNBVH_PRIM_ALPHA_PATCH_FLIPPED || kind == NNBVH_PRIM_ALPHA_PATCH_SMOOTH_FLIPPED;
-}
+// alpha-tested bilinear patches: kind = 8 + flipped + 2 * smooth + 4 * uv
+constexpr bool is_alpha_patch_kind(int kind) { return kind >= NNBVH_PRIM_ALPHA_PATCH && kind <= NNBVH_PRIM_ALPHA_PATCH_UV_SMOOTH_FLIPPED; }
+constexpr bool is_smooth_alpha_patch_kind(int kind) { return is_alpha_patch_kind(kind) && ((kind - NNBVH_PRIM_ALPHA_PATCH) & 2); }
+constexpr bool is_flipped_alpha_patch_kind(int kind) { return is_alpha_patch_kind(kind) && ((kind - NNBVH_PRIM_ALPHA_PATCH) & 1); }
+constexpr bool is_uv_alpha_patch_kind(int kind) { return is_alpha_patch_kind(kind) && ((kind - NNBVH_PRIM_ALPHA_PATCH) & 4); }
+constexpr int alpha_patch_slots(int kind) { return 4 + (is_smooth_alpha_patch_kind(kind) ? 4 : 0) + (is_uv_alpha_patch_kind(kind) ? 2 : 0); }
 inline bool is_flat_alpha_kind(int kind) {
     return kind == NNBVH_PRIM_ALPHA_TRIANGLE || kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED;
 }

@@ -155,12 +155,36 @@ DEV V3 lerp_v3(float t, V3 a, V3 b) {  // (1 - t) * a + t * b: vecmath.h:410-412
     const float s = 1 - t;
     return {s * a.x + t * b.x, s * a.y + t * b.y, s * a.z + t * b.z};
 }
+// hasUV = the mesh has (u, v) coordinates (uvA = {uv00, uv10}, uvB = {uv01, uv11}): dpdu / dpdv become the
+// derivatives with respect to (s, t), shapes.h:1414-1437, before the normal is taken
 DEV V3 patch_retrace_origin(V3 p00, V3 p10, V3 p01, V3 p11, float u, float v, bool flip, V3 d, bool smooth, V3 n00,
-                            V3 n10, V3 n01, V3 n11) {
+                            V3 n10, V3 n01, V3 n11, bool hasUV = false, float4 uvA = {0, 0, 0, 0},
+                            float4 uvB = {0, 0, 0, 0}) {
     const V3 a = lerp_v3(v, p00, p01), b = lerp_v3(v, p10, p11);
     const V3 ph = lerp_v3(u, a, b);
-    const V3 dpdu = sub(b, a);
-    const V3 dpdv = sub(lerp_v3(u, p01, p11), lerp_v3(u, p00, p10));
+    V3 dpdu = sub(b, a);
+    V3 dpdv = sub(lerp_v3(u, p01, p11), lerp_v3(u, p00, p10));
+    if (hasUV) {
+        const float sv = 1 - v, su = 1 - u;
+        const float s0x = sv * uvA.x + v * uvB.x, s0y = sv * uvA.y + v * uvB.y;  // Lerp(v, uv00, uv01)
+        const float s1x = sv * uvA.z + v * uvB.z, s1y = sv * uvA.w + v * uvB.w;  // Lerp(v, uv10, uv11)
+        const float dstdu0 = s1x - s0x, dstdu1 = s1y - s0y;
+        const float t0x = su * uvB.x + u * uvB.z, t0y = su * uvB.y + u * uvB.w;  // Lerp(u, uv01, uv11)
+        const float t1x = su * uvA.x + u * uvA.z, t1y = su * uvA.y + u * uvA.w;  // Lerp(u, uv00, uv10)
+        const float dstdv0 = t0x - t1x, dstdv1 = t0y - t1y;
+        const float duds = __builtin_fabsf(dstdu0) < 1e-8f ? 0 : 1 / dstdu0;
+        const float dvds = __builtin_fabsf(dstdv0) < 1e-8f ? 0 : 1 / dstdv0;
+        const float dudt = __builtin_fabsf(dstdu1) < 1e-8f ? 0 : 1 / dstdu1;
+        const float dvdt = __builtin_fabsf(dstdv1) < 1e-8f ? 0 : 1 / dstdv1;
+        const V3 dpds = {duds * dpdu.x + dvds * dpdv.x, duds * dpdu.y + dvds * dpdv.y, duds * dpdu.z + dvds * dpdv.z};
+        V3 dpdt = {dudt * dpdu.x + dvdt * dpdv.x, dudt * dpdu.y + dvdt * dpdv.y, dudt * dpdu.z + dvdt * dpdv.z};
+        const V3 c1 = cross(dpds, dpdt);
+        if (c1.x != 0 || c1.y != 0 || c1.z != 0) {
+            if (dot(cross(dpdu, dpdv), c1) < 0) dpdt = {-dpdt.x, -dpdt.y, -dpdt.z};
+            dpdu = dpds;
+            dpdv = dpdt;
+        }
+    }
     constexpr float g6 = gamma_f(6);
     const V3 pe = {g6 * (((__builtin_fabsf(p00.x) + __builtin_fabsf(p01.x)) + __builtin_fabsf(p10.x)) + __builtin_fabsf(p11.x)),
                    g6 * (((__builtin_fabsf(p00.y) + __builtin_fabsf(p01.y)) + __builtin_fabsf(p10.y)) + __builtin_fabsf(p11.y)),

@@ -659,15 +659,17 @@ void orc_offset_ray_origin(const float lo[3], const float hi[3], const float n[3
 static const float *g_vertex_normals = NULL; /* 3 floats per vertex, indexed like verts; kinds 6 / 7 read it */
 void orc_set_vertex_normals(const float *normals) { g_vertex_normals = normals; }
 
-/* prim kinds 8 .. 11: a BILINEAR PATCH behind such a GeometricPrimitive (9 / 11 = flipped orientation, 10 / 11 = the
- * mesh has per-vertex normals; meshes with (u, v) coordinates are not covered: their geometric normal depends on the
- * (s, t) reparametrisation, shapes.h:1414-1437).  The constant alpha comes from a per-primitive array
+/* prim kinds 8 .. 15 = 8 + flipped + 2 * smooth + 4 * uv: a BILINEAR PATCH behind such a GeometricPrimitive (flipped
+ * orientation; the mesh has per-vertex normals; the mesh has (u, v) coordinates, whose (s, t) reparametrisation the
+ * interaction's normal then goes through, shapes.h:1414-1437).  The constant alpha comes from a per-primitive array
  * (orc_set_prim_alpha: the patch needs all four v[]).  A non-planar patch CAN be met again by the ray spawned
  * off its own surface, so the recursion of :63-69 is real here: it is followed for up to ORC_ALPHA_PATCH_DEPTH
  * re-traces (a doubly ruled quadric meets a line twice at most; a third re-trace that still hits is numerical
  * self-intersection), beyond which the record is void and the caller re-traces the ray (*host_io = 1).
  * siNext->tHit += si->tHit (:67-68) unwinds from the deepest level: ((t_k + t_{k-1}) + ...) + t_0. */
 #define ORC_ALPHA_PATCH_DEPTH 3
+static const float *g_vertex_uvs = NULL; /* 2 floats per vertex; kinds 12 .. 15 (8 + flipped + 2 smooth + 4 uv) read it */
+void orc_set_vertex_uvs(const float *uvs) { g_vertex_uvs = uvs; }
 static const float *g_prim_alpha = NULL;
 static const orc_prim *g_prim_alpha_base = NULL;
 void orc_set_prim_alpha(const float *alpha) { g_prim_alpha = alpha; }
@@ -677,8 +679,9 @@ int orc_patch_interaction(const float p12[12], const float *uv8, const float *n1
 static int alpha_patch_intersect(const orc_prim *p, const float *verts, const float o[3], const float d[3],
                                  float tmax, float res[4], int *tests, int *host_io) {
     const float a = g_prim_alpha ? g_prim_alpha[p - g_prim_alpha_base] : 1.0f;
-    const int smooth = (p->kind == 10 || p->kind == 11) && g_vertex_normals;
-    const int flip = p->kind == 9 || p->kind == 11;
+    const int smooth = ((p->kind - 8) & 2) && g_vertex_normals;
+    const int flip = (p->kind - 8) & 1;
+    const int has_uv = ((p->kind - 8) & 4) && g_vertex_uvs;
     float oc[3] = {o[0], o[1], o[2]}, tm = tmax, ts[ORC_ALPHA_PATCH_DEPTH];
     int k = 0;
     for (;;) {
@@ -701,11 +704,13 @@ static int alpha_patch_intersect(const orc_prim *p, const float *verts, const fl
             return 0;
         }
         ts[k++] = r[3];
-        float p12[12], n12[12], wo[3] = {-d[0], -d[1], -d[2]}, rec[50], on[3];
+        float p12[12], n12[12], uv8[8], wo[3] = {-d[0], -d[1], -d[2]}, rec[50], on[3];
         for (int j = 0; j < 4; ++j) memcpy(p12 + 3 * j, verts + 3 * (size_t)p->v[j], 12);
         if (smooth)
             for (int j = 0; j < 4; ++j) memcpy(n12 + 3 * j, g_vertex_normals + 3 * (size_t)p->v[j], 12);
-        orc_patch_interaction(p12, NULL, smooth ? n12 : NULL, flip, r, wo, 0.0f, 0, rec);
+        if (has_uv)
+            for (int j = 0; j < 4; ++j) memcpy(uv8 + 2 * j, g_vertex_uvs + 2 * (size_t)p->v[j], 8);
+        orc_patch_interaction(p12, has_uv ? uv8 : NULL, smooth ? n12 : NULL, flip, r, wo, 0.0f, 0, rec);
         orc_offset_ray_origin(rec + 38, rec + 41, rec + 11, d, on); /* rNext = si->intr.SpawnRay(r.d) */
         memcpy(oc, on, 12);
         tm = tm - r[3]; /* Intersect(rNext, tMax - si->tHit) */
@@ -714,7 +719,7 @@ static int alpha_patch_intersect(const orc_prim *p, const float *verts, const fl
 
 static int alpha_intersect(const orc_prim *p, const float *verts, const float o[3], const float d[3],
                            float tmax, float res[4], int *tests, int *host_io) {
-    if (p->kind >= 8 && p->kind <= 11) return alpha_patch_intersect(p, verts, o, d, tmax, res, tests, host_io);
+    if (p->kind >= 8 && p->kind <= 15) return alpha_patch_intersect(p, verts, o, d, tmax, res, tests, host_io);
     float r[4];
     ++*tests;
     if (!prim_test(p, verts, o, d, tmax, r)) return 0; /* :52-54 */
@@ -784,7 +789,7 @@ static void closest_tree(const orc_node *nodes, const orc_prim *prims, const flo
                         continue;
                     }
                     int primHit;
-                    if (p->kind >= 4 && p->kind <= 11) {
+                    if (p->kind >= 4 && p->kind <= 15) {
                         primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests, host_io);
                     } else {
                         ++tests;
@@ -871,7 +876,7 @@ static int any_tree(const orc_node *nodes, const orc_prim *prims, const float *v
                         continue;
                     }
                     int primHit; /* GeometricPrimitive::IntersectP with alpha = Intersect(...).has_value(), :79-81 */
-                    if (p->kind >= 4 && p->kind <= 11) {
+                    if (p->kind >= 4 && p->kind <= 15) {
                         primHit = alpha_intersect(p, verts, o, d, tmax, r, &tests, host_io);
                     } else {
                         ++tests;
@@ -1775,7 +1780,7 @@ static void kd_one(const orc_kd_node *nodes, const int32_t *prim_indices, const 
                         continue;
                     }
                     int primHit; /* GeometricPrimitive with a constant alpha: cpu/primitive.cpp:57-70, 79-81 */
-                    if (p->kind >= 4 && p->kind <= 11) {
+                    if (p->kind >= 4 && p->kind <= 15) {
                         primHit = alpha_intersect(p, verts, o, d, rayTMax, r, &tests, &host);
                     } else {
                         ++tests;

@@ -173,8 +173,10 @@ void orc_set_sin_mode(int mode);
  * triangles of smooth meshes); NULL = none.  The pointer is kept: it must outlive the traces that use it. */
 void orc_set_vertex_normals(const float *normals);
 /* constant alpha per primitive (one float per entry of the prims array handed to orc_intersect_closest / _any)
- * for prim kinds 8 .. 11 (alpha-tested bilinear patches; 10 / 11 also read the vertex normals); NULL = none */
+ * for prim kinds 8 .. 15 (alpha-tested bilinear patches: 8 + flipped + 2 * smooth + 4 * uv); NULL = none */
 void orc_set_prim_alpha(const float *alpha);
+/* (u, v) per vertex (2 floats, indexed like verts) for prim kinds 12 .. 15; NULL = none */
+void orc_set_vertex_uvs(const float *uvs);
 void orc_anim_interpolate_batch(const orc_anim *a, const float *time, int n, float *out32);
 /* two-level traversal with AnimatedPrimitive instances (cpu/primitive.cpp:133-158): anims[k] belongs to
  * instances[k]; entries with actually_animated == 0 are TransformedPrimitives */

@@ -59,7 +59,7 @@ def draw_scene(rng):
         patch = prims["kind"] == 1
         prim_alpha = None
         if patch.any() and rng.random() < 0.7:
-            pk = rng.choice(np.array([1, 8, 9, 10, 11], np.int32), len(prims))
+            pk = rng.choice(np.array([1, 8, 9, 10, 11, 12, 13, 14, 15], np.int32), len(prims))
             prims["kind"] = np.where(patch, pk, prims["kind"])
             prim_alpha = alpha
             if normals is None:
@@ -71,6 +71,14 @@ def draw_scene(rng):
                 verts[corner] += rng.uniform(-1.0, 1.0, size=(len(corner), 3)).astype(np.float32)
         return verts, prims, normals, prim_alpha
     return verts, prims, None, None
+
+
+def draw_uvs(rng, verts):
+    """(u, v) per vertex for the alpha-tested patches of meshes with uv (kinds 12 .. 15): random, some coincident"""
+    uv = rng.random((len(verts), 2)).astype(np.float32)
+    uv[rng.random(len(verts)) < 0.08] = np.float32(0.5)
+    uv[rng.random(len(verts)) < 0.05, 0] = np.float32(0.25)
+    return uv
 
 
 def draw_rays(rng, verts, prims, n):
@@ -219,9 +227,11 @@ def main():
         max_prims = int(rng.choice([1, 2, 4, 8]))
         tree = build_tree(prims, verts, max_prims, split)
         a_ord = None if prim_alpha is None else prim_alpha[tree.ordered_prims["id"]]
-        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals, prim_alpha=a_ord)
+        uvs = None if prim_alpha is None else draw_uvs(rng, verts)
+        agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals, prim_alpha=a_ord, uvs=uvs)
         ob.set_vertex_normals(normals)
         ob.set_prim_alpha(a_ord)
+        ob.set_vertex_uvs(uvs)
         if rng.random() < 0.3:
             agg.set_option("stack_window", int(rng.choice([4, 16])))
         rays = draw_rays(rng, verts, prims, args.rays)

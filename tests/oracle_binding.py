@@ -332,6 +332,16 @@ _normals_keepalive = None
 _alpha_keepalive = None
 
 
+_uvs_keepalive = None
+
+
+def set_vertex_uvs(uvs):
+    """(u, v) per vertex for prim kinds 12 .. 15 (alpha-tested patches of meshes with uv); None = none."""
+    global _uvs_keepalive
+    _uvs_keepalive = None if uvs is None else np.ascontiguousarray(uvs, np.float32)
+    lib().orc_set_vertex_uvs(None if uvs is None else _p(_uvs_keepalive))
+
+
 def set_prim_alpha(alpha):
     """Constant alpha per primitive for prim kinds 8 .. 11 (alpha-tested bilinear patches), indexed like the prims
     array given to closest() / any_hit(); None = none."""

@@ -210,7 +210,8 @@ def alpha_patch_scene(seed=31, n_tris=1500, n_patches=2500):
     prims = prims.copy()
     kinds = prims["kind"].copy()
     kinds[:n_tris] = rng.choice(np.array([0, 4, 5], np.int32), n_tris, p=[0.4, 0.3, 0.3])
-    kinds[n_tris:] = rng.choice(np.array([1, 8, 9, 10, 11], np.int32), n_patches, p=[0.2, 0.2, 0.2, 0.2, 0.2])
+    kinds[n_tris:] = rng.choice(np.array([1, 8, 9, 10, 11, 12, 13, 14, 15], np.int32), n_patches,
+                                p=[0.12] + [0.11] * 8)
     alpha = rng.choice(np.array([0.0, 0.25, 0.5, 0.9, 1.0, 1.5, -0.5], np.float32), len(prims))
     prims["kind"] = kinds
     tri_alpha = (kinds == 4) | (kinds == 5)
@@ -221,14 +222,27 @@ def alpha_patch_scene(seed=31, n_tris=1500, n_patches=2500):
     return verts, prims, normals, alpha, kinds
 
 
+def patch_uvs(verts, seed=3):
+    """(u, v) per vertex: random, with a few coincident pairs so that the 1e-8 derivative tests of shapes.h:1423-1426
+    and the cross(dpds, dpdt) == 0 fallback are reached"""
+    rng = np.random.default_rng(seed)
+    uv = rng.random((len(verts), 2)).astype(np.float32)
+    same = rng.random(len(verts)) < 0.08
+    uv[same] = np.float32(0.5)
+    uv[rng.random(len(verts)) < 0.05, 0] = np.float32(0.25)
+    return uv
+
+
 def _oracle_alpha_patch(tree, verts, normals, alpha_ordered, rays, nthreads=4):
     try:
         ob.set_vertex_normals(normals)
+        ob.set_vertex_uvs(patch_uvs(verts))
         ob.set_prim_alpha(alpha_ordered)
         h = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, nthreads)
         occ = ob.any_hit(tree.nodes, tree.ordered_prims, verts, rays, nthreads)
     finally:
         ob.set_vertex_normals(None)
+        ob.set_vertex_uvs(None)
         ob.set_prim_alpha(None)
     return h, occ
 
@@ -266,7 +280,7 @@ def test_oracle_alpha_patch_recursion():
     assert np.array_equal(occ == 1, h["prim"] >= 0)
     # the normals matter only through the offset direction: flat kinds (8 / 9) never read them
     flat_only = prims.copy()
-    flat_only["kind"] = np.where(kinds >= 10, kinds - 2, kinds)
+    flat_only["kind"] = np.where(kinds >= 8, 8 + ((kinds - 8) & ~2), kinds)  # the smooth bit off
     tf = build_tree(flat_only, verts)
     hf, _ = _oracle_alpha_patch(tf, verts, None, alpha[order], rays)
     hf2, _ = _oracle_alpha_patch(tf, verts, normals, alpha[order], rays)
@@ -311,16 +325,19 @@ def test_device_alpha_patches_equal_oracle():
         v[m] = rng.choice(special, int(m.sum()))
         weird[f] = v
     rays = np.concatenate([rays, weird])
+    uvs = patch_uvs(verts)
     with pytest.raises(NNBVHError, match="alpha"):
         BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals)
     with pytest.raises(NNBVHError, match="normals"):
-        BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, prim_alpha=a_ord)
-    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals, prim_alpha=a_ord)
+        BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, prim_alpha=a_ord, uvs=uvs)
+    with pytest.raises(NNBVHError, match="uvs"):
+        BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, prim_alpha=a_ord, normals=normals)
+    agg = BVHAggregate.from_tree(tree.nodes, tree.ordered_prims, verts, normals=normals, prim_alpha=a_ord, uvs=uvs)
     got = agg.Intersect(rays)
     occ, vis, tst = agg.IntersectP(rays, counts=True)
     exp, (eo, ev, et) = _oracle_alpha_patch(tree, verts, normals, a_ord, rays)
     # built on the device: the per-primitive alpha follows the primitives through the build (caller's order in)
-    dev = BVHAggregate.build_on_device(prims, verts, 4, "sah", normals=normals, prim_alpha=alpha)
+    dev = BVHAggregate.build_on_device(prims, verts, 4, "sah", normals=normals, prim_alpha=alpha, uvs=uvs)
     assert dev.Intersect(rays).tobytes() == got.tobytes()
     assert np.array_equal(dev.IntersectP(rays), occ)
     dev.close()
@@ -336,8 +353,8 @@ def test_device_alpha_patches_equal_oracle():
     assert np.array_equal(occ, eo) and np.array_equal(vis, ev) and np.array_equal(tst, et)
     assert np.array_equal(agg.IntersectP(rays), eo)
     hit_kind = kinds[np.maximum(exp["prim"], 0)]
-    for k in (8, 9, 10, 11):
-        assert ((hit_kind == k) & (exp["prim"] >= 0)).sum() > 300, k
+    for k in range(8, 16):
+        assert ((hit_kind == k) & (exp["prim"] >= 0)).sum() > 150, k
     # the twice-crossed patches are in the sample: more tests than the plain scene needs
     plain = prims.copy()
     plain["kind"] = np.where(kinds >= 8, 1, kinds)
