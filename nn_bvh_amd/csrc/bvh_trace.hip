@@ -70,8 +70,8 @@ constexpr int kEnter = (int)0x80000002;   // INST = 2: the lane waits to enter a
 // INST = 2: weight of a lane waiting to enter an AnimatedPrimitive in the step selection (interior = 16); 0 = enter
 // at once inside the primitive step (the round-2 form: 11 of 64 lanes active in the interpolation)
 // ALPHA = 2 (alpha-tested bilinear patches: the patch's interaction point and normal incl. the (s, t)
-// reparametrisation, the re-trace loop): 3 waves = 168 VGPRs with 9-14 spilled; 2 waves (no spills) measured 30 %
-// slower, 4 waves (more spills) no faster
+// reparametrisation, the re-trace loop): 158-162 VGPRs = 3 waves without spills; 2 waves measured 30 % slower,
+// 4 waves (22-27 spilled registers) no faster
 #ifndef NNBVH_MINW_ALPHA_PATCH
 #define NNBVH_MINW_ALPHA_PATCH 3
 #endif
@@ -373,24 +373,11 @@ void trace_kernel(TraceParams p) {
                         else if (k == 1) t1 = th;
                         else t2 = th;
                         ++k;
-                        V3 n00 = {0, 0, 0}, n10 = n00, n01 = n00, n11 = n00;
-                        if (flags & kPrimSmooth) {
-                            const float4 m0 = p.prims[slot + 4], m1 = p.prims[slot + 5], m2 = p.prims[slot + 6],
-                                         m3 = p.prims[slot + 7];
-                            n00 = {m0.x, m0.y, m0.z}, n10 = {m1.x, m1.y, m1.z}, n01 = {m2.x, m2.y, m2.z},
-                            n11 = {m3.x, m3.y, m3.z};
-                        }
-                        float4 uvA = {0, 0, 0, 0}, uvB = uvA;  // {uv00, uv10} {uv01, uv11}
-                        if (flags & kPrimUV) {
-                            const int at = slot + 4 + ((flags & kPrimSmooth) ? 4 : 0);
-                            uvA = p.prims[at];
-                            uvB = p.prims[at + 1];
-                        }
                         // rNext = si->intr.SpawnRay(r.d); Intersect(rNext, tMax - si->tHit)
                         rn.o = patch_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z},
                                                     {s3.x, s3.y, s3.z}, x0, x1, (flags & kPrimFlipN) != 0, rd,
-                                                    (flags & kPrimSmooth) != 0, n00, n10, n01, n11,
-                                                    (flags & kPrimUV) != 0, uvA, uvB);
+                                                    (flags & kPrimSmooth) != 0, (flags & kPrimUV) != 0,
+                                                    p.prims + slot + 4);
                         tm = tm - th;
                         tests += 1;
                     }

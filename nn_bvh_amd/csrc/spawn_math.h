@@ -157,14 +157,25 @@ DEV V3 lerp_v3(float t, V3 a, V3 b) {  // (1 - t) * a + t * b: vecmath.h:410-412
 }
 // hasUV = the mesh has (u, v) coordinates (uvA = {uv00, uv10}, uvB = {uv01, uv11}): dpdu / dpdv become the
 // derivatives with respect to (s, t), shapes.h:1414-1437, before the normal is taken
-DEV V3 patch_retrace_origin(V3 p00, V3 p10, V3 p01, V3 p11, float u, float v, bool flip, V3 d, bool smooth, V3 n00,
-                            V3 n10, V3 n01, V3 n11, bool hasUV = false, float4 uvA = {0, 0, 0, 0},
-                            float4 uvB = {0, 0, 0, 0}) {
+// `extra` = the slots after the patch's four: {n00} {n10} {n01} {n11} if smooth, then {uv00, uv10} {uv01, uv11} if
+// hasUV; they are read where they are needed (the (u, v) pair before the normal, the normals last) so that the
+// patch's 20 attribute words are never live together
+DEV V3 patch_retrace_origin(V3 p00, V3 p10, V3 p01, V3 p11, float u, float v, bool flip, V3 d, bool smooth, bool hasUV,
+                            const float4 *extra) {
     const V3 a = lerp_v3(v, p00, p01), b = lerp_v3(v, p10, p11);
     const V3 ph = lerp_v3(u, a, b);
     V3 dpdu = sub(b, a);
     V3 dpdv = sub(lerp_v3(u, p01, p11), lerp_v3(u, p00, p10));
+    constexpr float g6 = gamma_f(6);
+    const V3 pe = {g6 * (((__builtin_fabsf(p00.x) + __builtin_fabsf(p01.x)) + __builtin_fabsf(p10.x)) + __builtin_fabsf(p11.x)),
+                   g6 * (((__builtin_fabsf(p00.y) + __builtin_fabsf(p01.y)) + __builtin_fabsf(p10.y)) + __builtin_fabsf(p11.y)),
+                   g6 * (((__builtin_fabsf(p00.z) + __builtin_fabsf(p01.z)) + __builtin_fabsf(p10.z)) + __builtin_fabsf(p11.z))};
+    const V3 lo = {pe.x == 0 ? ph.x : next_down(ph.x + (-pe.x)), pe.y == 0 ? ph.y : next_down(ph.y + (-pe.y)),
+                   pe.z == 0 ? ph.z : next_down(ph.z + (-pe.z))};
+    const V3 hi = {pe.x == 0 ? ph.x : next_up(ph.x + pe.x), pe.y == 0 ? ph.y : next_up(ph.y + pe.y),
+                   pe.z == 0 ? ph.z : next_up(ph.z + pe.z)};
     if (hasUV) {
+        const float4 uvA = extra[smooth ? 4 : 0], uvB = extra[smooth ? 5 : 1];
         const float sv = 1 - v, su = 1 - u;
         const float s0x = sv * uvA.x + v * uvB.x, s0y = sv * uvA.y + v * uvB.y;  // Lerp(v, uv00, uv01)
         const float s1x = sv * uvA.z + v * uvB.z, s1y = sv * uvA.w + v * uvB.w;  // Lerp(v, uv10, uv11)
@@ -185,19 +196,13 @@ DEV V3 patch_retrace_origin(V3 p00, V3 p10, V3 p01, V3 p11, float u, float v, bo
             dpdv = dpdt;
         }
     }
-    constexpr float g6 = gamma_f(6);
-    const V3 pe = {g6 * (((__builtin_fabsf(p00.x) + __builtin_fabsf(p01.x)) + __builtin_fabsf(p10.x)) + __builtin_fabsf(p11.x)),
-                   g6 * (((__builtin_fabsf(p00.y) + __builtin_fabsf(p01.y)) + __builtin_fabsf(p10.y)) + __builtin_fabsf(p11.y)),
-                   g6 * (((__builtin_fabsf(p00.z) + __builtin_fabsf(p01.z)) + __builtin_fabsf(p10.z)) + __builtin_fabsf(p11.z))};
-    const V3 lo = {pe.x == 0 ? ph.x : next_down(ph.x + (-pe.x)), pe.y == 0 ? ph.y : next_down(ph.y + (-pe.y)),
-                   pe.z == 0 ? ph.z : next_down(ph.z + (-pe.z))};
-    const V3 hi = {pe.x == 0 ? ph.x : next_up(ph.x + pe.x), pe.y == 0 ? ph.y : next_up(ph.y + pe.y),
-                   pe.z == 0 ? ph.z : next_up(ph.z + pe.z)};
     const V3 c = cross(dpdu, dpdv);
     const float len = __builtin_sqrtf(len2(c));
     V3 n = {c.x / len, c.y / len, c.z / len};
     if (flip) n = {n.x * -1, n.y * -1, n.z * -1};
     if (smooth) {
+        const float4 m0 = extra[0], m1 = extra[1], m2 = extra[2], m3 = extra[3];
+        const V3 n00 = {m0.x, m0.y, m0.z}, n10 = {m1.x, m1.y, m1.z}, n01 = {m2.x, m2.y, m2.z}, n11 = {m3.x, m3.y, m3.z};
         const V3 a0 = lerp_v3(v, n00, n01), a1 = lerp_v3(v, n10, n11);
         V3 ns = lerp_v3(u, a0, a1);
         const float l2 = len2(ns);
