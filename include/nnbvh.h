@@ -86,7 +86,8 @@ typedef struct nnbvh_linear_node {
                                        ray re-traced off its own surface; the recursion of cpu/primitive.cpp:63-69 is
                                        followed for up to three re-traces, beyond which the record is void
                                        (needs-host).  For patch meshes WITHOUT (u, v) coordinates (with them: kinds
-                                       12 .. 15).  BVH scenes, single level */
+                                       12 .. 15).  BVH scenes (inside a kd-tree such primitives stay
+                                       NNBVH_PRIM_HOST) */
 #define NNBVH_PRIM_ALPHA_PATCH_FLIPPED 9         /* same, mesh->reverseOrientation ^ transformSwapsHandedness */
 #define NNBVH_PRIM_ALPHA_PATCH_SMOOTH 10         /* ... of a mesh WITH per-vertex normals (BilinearPatchMesh::n as
                                                      the mesh stores them, util/mesh.cpp:216-223) */
@@ -228,6 +229,13 @@ nnbvh_scene *nnbvh_scene_create_instanced_animated(const nnbvh_linear_node *node
                                                    int n_prims, const float *verts, int n_verts,
                                                    const nnbvh_instance *instances, int n_instances,
                                                    const nnbvh_animated_transform *animated, int device);
+/* ... and with the attributes the alpha-tested kinds read (nnbvh_scene_create_with_attributes): normals and uvs per
+ * vertex, prim_alpha per entry of `prims`; animated and each attribute array may be NULL */
+nnbvh_scene *nnbvh_scene_create_instanced_with_attributes(const nnbvh_linear_node *nodes, int n_nodes, int n_top_nodes,
+                                                          const nnbvh_prim *prims, int n_prims, const float *verts,
+                                                          int n_verts, const nnbvh_instance *instances, int n_instances,
+                                                          const nnbvh_animated_transform *animated, const float *normals,
+                                                          const float *uvs, const float *prim_alpha, int device);
 /* Transform::operator()(const Bounds3f&) (util/transform.cpp:134-139): the bounds an instance
  * primitive presents to the top-level builder (TransformedPrimitive::Bounds, primitive.h:94) */
 void nnbvh_transform_bounds(const float render_from_prim[12], const float in_min_max[6],

@@ -45,7 +45,7 @@ assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 32
 EXPORTS = [
     "nnbvh_last_error", "nnbvh_device_count", "nnbvh_build_create", "nnbvh_build_nodes",
     "nnbvh_build_ordered_prims", "nnbvh_build_depth", "nnbvh_build_destroy",
-    "nnbvh_scene_create", "nnbvh_scene_create_with_normals", "nnbvh_scene_create_with_attributes", "nnbvh_scene_create_gpu_build_with_attributes", "nnbvh_scene_destroy", "nnbvh_scene_bounds", "nnbvh_scene_info",
+    "nnbvh_scene_create", "nnbvh_scene_create_with_normals", "nnbvh_scene_create_with_attributes", "nnbvh_scene_create_gpu_build_with_attributes", "nnbvh_scene_create_instanced_with_attributes", "nnbvh_scene_destroy", "nnbvh_scene_bounds", "nnbvh_scene_info",
     "nnbvh_intersect_closest", "nnbvh_intersect_any", "nnbvh_intersect_closest_device",
     "nnbvh_intersect_any_device", "nnbvh_scene_set_option", "nnbvh_scene_sched_stats",
     "nnbvh_trace_batches_device", "nnbvh_scene_create_instanced", "nnbvh_transform_bounds",
@@ -107,6 +107,8 @@ def lib():
     L.nnbvh_scene_create.argtypes = [vp, i32, vp, i32, vp, i32, i32]
     L.nnbvh_scene_create_with_normals.restype = vp
     L.nnbvh_scene_create_with_normals.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32]
+    L.nnbvh_scene_create_instanced_with_attributes.restype = vp
+    L.nnbvh_scene_create_instanced_with_attributes.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32]
     L.nnbvh_scene_create_with_attributes.restype = vp
     L.nnbvh_scene_create_with_attributes.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32]
     L.nnbvh_scene_destroy.restype = None

@@ -176,7 +176,18 @@ class BVHAggregate:
         self.device = int(device)
         if instances is not None and len(instances):
             self.instances = np.ascontiguousarray(instances, _lib.INSTANCE_DTYPE)
-            if animated is not None:
+            if normals is not None or prim_alpha is not None or uvs is not None:
+                f32 = lambda a, w: None if a is None else np.ascontiguousarray(a, np.float32).reshape(-1, w)  # noqa: E731
+                self.normals, self.uvs = f32(normals, 3), f32(uvs, 2)
+                self.prim_alpha = None if prim_alpha is None else np.ascontiguousarray(prim_alpha, np.float32).reshape(-1)
+                self.animated = None if animated is None else np.ascontiguousarray(animated, _lib.ANIMATED_DTYPE)
+                opt = lambda a: ptr(a) if a is not None else None  # noqa: E731
+                self._h = L.nnbvh_scene_create_instanced_with_attributes(
+                    ptr(self.nodes), len(self.nodes), int(n_top_nodes), ptr(self.ordered_prims),
+                    len(self.ordered_prims), ptr(self.verts), len(self.verts), ptr(self.instances),
+                    len(self.instances), opt(self.animated), opt(self.normals), opt(self.uvs), opt(self.prim_alpha),
+                    self.device)
+            elif animated is not None:
                 self.animated = np.ascontiguousarray(animated, _lib.ANIMATED_DTYPE)
                 assert len(self.animated) == len(self.instances)
                 self._h = L.nnbvh_scene_create_instanced_animated(

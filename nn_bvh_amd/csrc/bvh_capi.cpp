@@ -418,11 +418,6 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
                           "(nnbvh_scene_create_with_attributes)");
                 return nullptr;
             }
-            if (n_instances > 0) {
-                set_error("scene_create: NNBVH_PRIM_ALPHA_PATCH primitives are for single-level scenes "
-                          "(inside two-level scenes they stay NNBVH_PRIM_HOST)");
-                return nullptr;
-            }
         } else if (is_triangle_kind(p.kind)) nv = nslots = 3;
         else if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) nv = nslots = 4;
         else if (p.kind == NNBVH_PRIM_HOST) {
@@ -463,7 +458,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
                                     : (int32_t) ~(uint32_t)slot_of[(size_t)nodes[i].offset];
     };
     std::vector<float> stream((size_t)n_slots * 4, 0.0f);
-    bool has_host = false, has_alpha = false;
+    bool has_host = false, has_alpha = false, has_alpha_patch = false;
     for (int k = 0; k < n_prims; ++k) {
         const nnbvh_prim &p = prims[k];
         float *s = &stream[(size_t)slot_of[(size_t)k] * 4];
@@ -492,6 +487,23 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
         const int nv = is_triangle_kind(p.kind) ? 3 : 4;
         for (int j = 0; j < nv; ++j) put3(s, 4 * j, verts + 3 * (size_t)p.v[j]);
         if (p.kind == NNBVH_PRIM_BILINEAR_PATCH) flags |= kPrimPatch;
+        if (is_alpha_patch_kind(p.kind)) {  // as k_bake_stream lays them out (bvh_bake.hip)
+            flags |= kPrimPatch | kPrimAlpha | (is_flipped_alpha_patch_kind(p.kind) ? kPrimFlipN : 0u);
+            s[11] = prim_alpha[k];
+            has_alpha = has_alpha_patch = true;
+            if (is_smooth_alpha_patch_kind(p.kind)) {
+                flags |= kPrimSmooth;
+                for (int j = 0; j < 4; ++j) put3(s, 16 + 4 * j, normals + 3 * (size_t)p.v[j]);
+            }
+            if (is_uv_alpha_patch_kind(p.kind)) {
+                flags |= kPrimUV;
+                float *u = s + (is_smooth_alpha_patch_kind(p.kind) ? 32 : 16);
+                for (int j = 0; j < 4; ++j) {
+                    u[2 * j] = uvs[2 * (size_t)p.v[j]];
+                    u[2 * j + 1] = uvs[2 * (size_t)p.v[j] + 1];
+                }
+            }
+        }
         if (is_flat_alpha_kind(p.kind) || is_smooth_alpha_kind(p.kind)) {
             flags |= kPrimAlpha;
             if (p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED || p.kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED) flags |= kPrimFlipN;
@@ -547,7 +559,7 @@ static nnbvh_scene *create_scene(const nnbvh_linear_node *nodes, int n_nodes, in
     s->root_ref = ref_of(0);
     s->instanced = n_instances > 0 ? 1 : 0;
     s->has_host_prims = (has_host || has_alpha) ? 1 : 0;  // an alpha re-trace that hits voids the ray like a host primitive
-    s->has_alpha = has_alpha ? 1 : 0;
+    s->has_alpha = has_alpha_patch ? 2 : (has_alpha ? 1 : 0);
     s->has_patches = 1;  // two-level scenes always run the general kernels
     s->max_grid_threads = s->n_cus * 8 * kBlockThreads;
     // one allocation, as bake_on_device makes it: records, then the 256-B aligned primitive stream + 64 B
@@ -711,6 +723,21 @@ nnbvh_scene *nnbvh_scene_create_instanced_animated(const nnbvh_linear_node *node
             }
     return create_scene(nodes, n_nodes, n_top_nodes, prims, n_prims, verts, n_verts, instances,
                         n_instances, device, animated);
+}
+
+nnbvh_scene *nnbvh_scene_create_instanced_with_attributes(const nnbvh_linear_node *nodes, int n_nodes, int n_top_nodes,
+                                                          const nnbvh_prim *prims, int n_prims, const float *verts,
+                                                          int n_verts, const nnbvh_instance *instances, int n_instances,
+                                                          const nnbvh_animated_transform *animated, const float *normals,
+                                                          const float *uvs, const float *prim_alpha, int device) {
+    if (animated)
+        for (int k = 0; k < n_instances; ++k)
+            if (animated[k].actually_animated && !(animated[k].end_time > animated[k].start_time)) {
+                set_error("scene_create: animated instance with an empty time range");
+                return nullptr;
+            }
+    return create_scene(nodes, n_nodes, n_top_nodes, prims, n_prims, verts, n_verts, instances, n_instances, device,
+                        animated, normals, prim_alpha, uvs);
 }
 
 void nnbvh_transform_bounds(const float m[12], const float in[6], float out[6]) {

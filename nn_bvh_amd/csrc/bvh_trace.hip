@@ -789,9 +789,10 @@ static hipError_t launch_mode(const TraceParams &p, int window, int instanced, i
     // scenes with alpha-tested triangles and two-level scenes: one instance of the kernel each (window 8)
     // INST: 0 single-level, 1 static instances, 2 instances with AnimatedPrimitives among them (the
     // interpolation of the transform costs 60 VGPRs: 160-177 against 98-116, 2 against 3 wavefronts per SIMD)
-    if (patches & 4) {  // alpha-tested bilinear patches: single-level scenes only (scene creation sees to it)
-        if (instanced) return hipErrorInvalidValue;
-        return launch_one<MODE, 8, 0, 1, 2>(p, blocks, stream, occupancy);
+    if (patches & 4) {  // alpha-tested bilinear patches
+        if (!instanced) return launch_one<MODE, 8, 0, 1, 2>(p, blocks, stream, occupancy);
+        return p.anim ? launch_one<MODE, 8, 2, 1, 2>(p, blocks, stream, occupancy)
+                      : launch_one<MODE, 8, 1, 1, 2>(p, blocks, stream, occupancy);
     }
     if (patches & 2) {
         if (!instanced) return launch_one<MODE, 8, 0, 1, 1>(p, blocks, stream, occupancy);

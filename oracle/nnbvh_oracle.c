@@ -1011,6 +1011,7 @@ void orc_intersect_any(const orc_node *nodes, int n_nodes, const orc_prim *prims
 void orc_intersect_closest_inst(const orc_node *nodes, const orc_prim *prims, const float *verts,
                                 const orc_instance *instances, const orc_ray *rays, int64_t n,
                                 orc_hit *hits, int nthreads) {
+    g_prim_alpha_base = prims; /* alpha-tested patches index orc_set_prim_alpha's array by position */
     orc_job j;
     memset(&j, 0, sizeof j);
     j.nodes = nodes;
@@ -1026,6 +1027,7 @@ void orc_intersect_any_inst(const orc_node *nodes, const orc_prim *prims, const 
                             const orc_instance *instances, const orc_ray *rays, int64_t n,
                             uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests,
                             int nthreads) {
+    g_prim_alpha_base = prims; /* alpha-tested patches index orc_set_prim_alpha's array by position */
     orc_job j;
     memset(&j, 0, sizeof j);
     j.nodes = nodes;
@@ -1043,6 +1045,7 @@ void orc_intersect_any_inst(const orc_node *nodes, const orc_prim *prims, const 
 void orc_intersect_closest_anim(const orc_node *nodes, const orc_prim *prims, const float *verts,
                                 const orc_instance *instances, const orc_anim *anims, const orc_ray *rays,
                                 int64_t n, orc_hit *hits, int nthreads) {
+    g_prim_alpha_base = prims; /* alpha-tested patches index orc_set_prim_alpha's array by position */
     orc_job j;
     memset(&j, 0, sizeof j);
     j.nodes = nodes;
@@ -1059,6 +1062,7 @@ void orc_intersect_any_anim(const orc_node *nodes, const orc_prim *prims, const 
                             const orc_instance *instances, const orc_anim *anims, const orc_ray *rays,
                             int64_t n, uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests,
                             int nthreads) {
+    g_prim_alpha_base = prims; /* alpha-tested patches index orc_set_prim_alpha's array by position */
     orc_job j;
     memset(&j, 0, sizeof j);
     j.nodes = nodes;

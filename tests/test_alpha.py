@@ -363,3 +363,66 @@ def test_device_alpha_patches_equal_oracle():
     second = (exp["prim"] >= 0) & (exp["prim"] == hp["prim"]) & (exp["t"] > hp["t"] * 1.0001) & (hit_kind >= 8)
     assert second.sum() > 20
     agg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("animated", [False, True])
+def test_device_alpha_patches_and_smooth_triangles_inside_instances(animated):
+    """nnbvh_scene_create_instanced_with_attributes: the alpha-tested kinds that read per-vertex normals / uvs and the
+    per-primitive alpha (smooth triangles 6 / 7, patches 8 .. 15) inside TransformedPrimitive / AnimatedPrimitive
+    instances — the alpha test hashes the instance-space ray, the re-trace runs in instance space."""
+    from nn_bvh_amd import BVHAggregate, instancing
+    from test_oracle_vs_reference_live import random_affine
+    verts, prims, normals, alpha, kinds = alpha_patch_scene(41, 500, 700)
+    rng = np.random.default_rng(3)
+    prims = prims.copy()
+    tri_alpha = (kinds == 4) | (kinds == 5)
+    smooth = tri_alpha & (rng.random(len(prims)) < 0.5)
+    prims["kind"] = np.where(smooth, kinds + 2, kinds)   # some of the alpha triangles on a smooth mesh
+    uvs = patch_uvs(verts)
+    anims = oa = None
+    if animated:
+        import test_animated as ta
+        _, _, _, _, _, _, anims, oa, placements = ta.animated_scene(4, 24)
+        nodes, aprims, instances, n_top = ta.rebuild_with_motion_bounds(verts, prims, placements, anims, oa)
+    else:
+        n_place = 6
+        M, _ = random_affine(rng, n_place)
+        M[:, :3, 3] = rng.uniform(-15, 15, size=(n_place, 3))
+        Mi = np.linalg.inv(M.astype(np.float64)).astype(np.float32)
+        placements = [(0, M[j, :3].reshape(12), Mi[j, :3].reshape(12)) for j in range(n_place)]
+        nodes, aprims, instances, n_top = instancing.assemble_two_level(prims[:0], verts, [prims], placements)
+    obj = aprims["kind"] != 2
+    a_ord = np.zeros(len(aprims), np.float32)
+    a_ord[obj] = alpha[aprims["id"][obj]]   # the object's primitives keep their ids = positions in `prims`
+    assert np.array_equal(aprims["kind"][obj], prims["kind"][aprims["id"][obj]])
+    rays = scene.random_rays(60000, [-25, -25, -25], [25, 25, 25], 13)
+    if animated:
+        rays["time"] = np.random.default_rng(6).uniform(-0.2, 1.2, len(rays)).astype(np.float32)
+    agg = BVHAggregate.from_tree(nodes, aprims, verts, instances=instances, n_top_nodes=n_top, animated=anims,
+                                 normals=normals, uvs=uvs, prim_alpha=a_ord)
+    got = agg.Intersect(rays)
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    try:
+        ob.set_vertex_normals(normals)
+        ob.set_vertex_uvs(uvs)
+        ob.set_prim_alpha(a_ord)
+        if animated:
+            ob.set_sin_mode(1)  # the device's sine (the path's documented exception, tests/test_animated.py)
+            exp = ob.closest_anim(nodes, aprims, verts, instances, oa, rays, 4)
+            eo, ev, et = ob.any_hit_anim(nodes, aprims, verts, instances, oa, rays, 4)
+        else:
+            exp = ob.closest_inst(nodes, aprims, verts, instances, rays, 4)
+            eo, ev, et = ob.any_hit_inst(nodes, aprims, verts, instances, rays, 4)
+    finally:
+        ob.set_sin_mode(0)
+        ob.set_vertex_normals(None)
+        ob.set_vertex_uvs(None)
+        ob.set_prim_alpha(None)
+    assert got.tobytes() == exp.tobytes()
+    assert np.array_equal(occ, eo) and np.array_equal(vis, ev) and np.array_equal(tst, et)
+    hit_kind = prims["kind"][np.maximum(exp["prim"], 0)]
+    inside = (exp["prim"] >= 0) & (exp["instance"] > 0)
+    for k in (6, 7, 8, 11, 12, 15):
+        assert (inside & (hit_kind == k)).sum() > 20, k
+    agg.close()
