@@ -953,8 +953,9 @@ static Workspace *workspace_for(nnbvh_scene *s, hipStream_t stream) {
 
 static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void *d_hits,
                   void *d_occ, void *d_vis, void *d_tests, hipStream_t stream, Workspace *w,
-                  const int32_t *d_n = nullptr) {
-    TraceParams p;
+                  const int32_t *d_n = nullptr, const nnbvh_ray_soa *soa = nullptr) {
+    TraceParams p{};
+    if (soa) p.soa = *soa;  // d_rays == nullptr: the kernel reads the queue's SOA slices itself
     p.wide = s->d_wide;
     p.prims = s->d_prims;
     std::memcpy(p.rootMin, s->bounds, 12);
@@ -992,6 +993,11 @@ static int launch(nnbvh_scene *s, int mode, const void *d_rays, int64_t n, void 
                 "trace kernel launch"))
         return NNBVH_ERR_DEVICE;
     return NNBVH_OK;
+}
+
+// the lean kernel instances (bvh_trace.hip) have forms that read a wavefront queue's SOA slices themselves
+static bool scene_runs_lean(const nnbvh_scene *s) {
+    return !s->instanced && patch_bits(s) == 0 && !s->has_host_prims && scene_fits32(s) && s->window == 8;
 }
 
 static bool grow(void **ptr, size_t *have, size_t need, const char *what) {
@@ -1049,7 +1055,7 @@ int nnbvh_intersect_any_device(nnbvh_scene *s, const void *d_rays, int64_t n, vo
 // One mode-3 launch over up to kMaxFusedBatches closest-hit / occlusion-only batches (the caller has checked that
 // the scene and the batches allow it).  d_n: nullable array of nullable device-resident batch sizes.
 static int launch_fused_batches(nnbvh_scene *s, Workspace *w, hipStream_t stream, const nnbvh_batch *batches,
-                                int n_batches, const int32_t *const *d_n) {
+                                int n_batches, const int32_t *const *d_n, const nnbvh_ray_soa *const *soas = nullptr) {
     TraceParams p{};
     p.wide = s->d_wide;
     p.prims = s->d_prims;
@@ -1077,6 +1083,7 @@ static int launch_fused_batches(nnbvh_scene *s, Workspace *w, hipStream_t stream
         p.bOut[b] = batches[i].d_out;
         p.bN[b] = (long)batches[i].n;
         p.bNDev[b] = d_n ? d_n[i] : nullptr;
+        if (soas && soas[i]) p.bSoa[b] = *soas[i];  // with d_rays == nullptr: read as SOA slices
         if (batches[i].kind == NNBVH_BATCH_ANY) p.anyMask |= 1u << b;
         total += batches[i].n;
     }
@@ -1195,13 +1202,19 @@ int nnbvh_wavefront_intersect_closest(nnbvh_scene *s, int32_t max_rays, const nn
     hipStream_t stream = (hipStream_t)stream_;
     Workspace *w = workspace_for(s, stream);
     if (!w) return NNBVH_ERR_DEVICE;
-    if (!grow(&w->d_in, &w->in_bytes, (size_t)max_rays * sizeof(nnbvh_ray), "hipMalloc(wavefront rays)"))
-        return NNBVH_ERR_DEVICE;
     const WavefrontCount cnt{max_rays, d_size};
     const int max_blocks = s->n_cus * 8;
-    if (!hip_ok(launch_wf_gather(*ray_queue, cnt, w->d_in, max_blocks, stream), "gather kernel launch"))
-        return NNBVH_ERR_DEVICE;
-    const int rc = launch(s, 0, w->d_in, max_rays, d_hits, nullptr, nullptr, nullptr, stream, w, d_size);
+    int rc;
+    if (scene_runs_lean(s)) {
+        // the traversal kernel reads the queue's SOA slices itself (no gather pass into nnbvh_ray records)
+        rc = launch(s, 0, nullptr, max_rays, d_hits, nullptr, nullptr, nullptr, stream, w, d_size, ray_queue);
+    } else {
+        if (!grow(&w->d_in, &w->in_bytes, (size_t)max_rays * sizeof(nnbvh_ray), "hipMalloc(wavefront rays)"))
+            return NNBVH_ERR_DEVICE;
+        if (!hip_ok(launch_wf_gather(*ray_queue, cnt, w->d_in, max_blocks, stream), "gather kernel launch"))
+            return NNBVH_ERR_DEVICE;
+        rc = launch(s, 0, w->d_in, max_rays, d_hits, nullptr, nullptr, nullptr, stream, w, d_size);
+    }
     if (rc != NNBVH_OK) return rc;
     if (!hip_ok(launch_wf_enqueue_closest(d_hits, cnt, ray_queue->has_medium, d_prim_class,
                                           (long)n_prim_class, *out, max_blocks, stream),
@@ -1226,8 +1239,6 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
     hipStream_t stream = (hipStream_t)stream_;
     Workspace *w = workspace_for(s, stream);
     if (!w) return NNBVH_ERR_DEVICE;
-    if (!grow(&w->d_in, &w->in_bytes, (size_t)max_rays * sizeof(nnbvh_ray), "hipMalloc(wavefront rays)"))
-        return NNBVH_ERR_DEVICE;
     uint8_t *occ = d_occluded;
     if (!occ) {
         if (!grow(&w->d_out, &w->out_bytes, (size_t)max_rays, "hipMalloc(wavefront occluded)"))
@@ -1236,9 +1247,16 @@ int nnbvh_wavefront_intersect_shadow(nnbvh_scene *s, int32_t max_rays, const nnb
     }
     const WavefrontCount cnt{max_rays, d_size};
     const int max_blocks = s->n_cus * 8;
-    if (!hip_ok(launch_wf_gather(*shadow_queue, cnt, w->d_in, max_blocks, stream), "gather kernel launch"))
-        return NNBVH_ERR_DEVICE;
-    const int rc = launch(s, 2, w->d_in, max_rays, nullptr, occ, nullptr, nullptr, stream, w, d_size);
+    int rc;
+    if (scene_runs_lean(s)) {
+        rc = launch(s, 2, nullptr, max_rays, nullptr, occ, nullptr, nullptr, stream, w, d_size, shadow_queue);
+    } else {
+        if (!grow(&w->d_in, &w->in_bytes, (size_t)max_rays * sizeof(nnbvh_ray), "hipMalloc(wavefront rays)"))
+            return NNBVH_ERR_DEVICE;
+        if (!hip_ok(launch_wf_gather(*shadow_queue, cnt, w->d_in, max_blocks, stream), "gather kernel launch"))
+            return NNBVH_ERR_DEVICE;
+        rc = launch(s, 2, w->d_in, max_rays, nullptr, occ, nullptr, nullptr, stream, w, d_size);
+    }
     if (rc != NNBVH_OK) return rc;
     if (!hip_ok(launch_wf_record_shadow(occ, cnt, d_Ld, d_r_u, d_r_l, d_pixel_index, d_L, (long)n_pixels,
                                         max_blocks, stream),
@@ -1284,27 +1302,35 @@ int nnbvh_wavefront_intersect_closest_and_shadow(
     hipStream_t stream = (hipStream_t)stream_;
     Workspace *w = workspace_for(s, stream);
     if (!w) return NNBVH_ERR_DEVICE;
-    const size_t closest_bytes = (size_t)max_rays * sizeof(nnbvh_ray);
-    if (!grow(&w->d_in, &w->in_bytes, closest_bytes + (size_t)max_shadow_rays * sizeof(nnbvh_ray),
-              "hipMalloc(wavefront rays)"))
-        return NNBVH_ERR_DEVICE;
     uint8_t *occ = d_occluded;
     if (!occ) {
         if (!grow(&w->d_out, &w->out_bytes, (size_t)max_shadow_rays, "hipMalloc(wavefront occluded)"))
             return NNBVH_ERR_DEVICE;
         occ = (uint8_t *)w->d_out;
     }
-    void *closest_rays = w->d_in, *shadow_rays = (char *)w->d_in + closest_bytes;
     const WavefrontCount cnt{max_rays, d_size}, scnt{max_shadow_rays, d_shadow_size};
     const int max_blocks = s->n_cus * 8;
-    if (!hip_ok(launch_wf_gather(*ray_queue, cnt, closest_rays, max_blocks, stream), "gather kernel launch") ||
-        !hip_ok(launch_wf_gather(*shadow_queue, scnt, shadow_rays, max_blocks, stream), "gather kernel launch"))
-        return NNBVH_ERR_DEVICE;
     // the (longer) closest-hit batch first: the shadow rays fill the lanes its tail leaves idle
-    const nnbvh_batch batches[2] = {{NNBVH_BATCH_CLOSEST, 0, closest_rays, max_rays, d_hits, nullptr, nullptr},
-                                    {NNBVH_BATCH_ANY, 0, shadow_rays, max_shadow_rays, occ, nullptr, nullptr}};
     const int32_t *sizes[2] = {d_size, d_shadow_size};
-    const int rc = launch_fused_batches(s, w, stream, batches, 2, sizes);
+    int rc;
+    if (scene_runs_lean(s)) {  // both queues are read as the SOA slices they are
+        const nnbvh_batch batches[2] = {{NNBVH_BATCH_CLOSEST, 0, nullptr, max_rays, d_hits, nullptr, nullptr},
+                                        {NNBVH_BATCH_ANY, 0, nullptr, max_shadow_rays, occ, nullptr, nullptr}};
+        const nnbvh_ray_soa *soas[2] = {ray_queue, shadow_queue};
+        rc = launch_fused_batches(s, w, stream, batches, 2, sizes, soas);
+    } else {
+        const size_t closest_bytes = (size_t)max_rays * sizeof(nnbvh_ray);
+        if (!grow(&w->d_in, &w->in_bytes, closest_bytes + (size_t)max_shadow_rays * sizeof(nnbvh_ray),
+                  "hipMalloc(wavefront rays)"))
+            return NNBVH_ERR_DEVICE;
+        void *closest_rays = w->d_in, *shadow_rays = (char *)w->d_in + closest_bytes;
+        if (!hip_ok(launch_wf_gather(*ray_queue, cnt, closest_rays, max_blocks, stream), "gather kernel launch") ||
+            !hip_ok(launch_wf_gather(*shadow_queue, scnt, shadow_rays, max_blocks, stream), "gather kernel launch"))
+            return NNBVH_ERR_DEVICE;
+        const nnbvh_batch batches[2] = {{NNBVH_BATCH_CLOSEST, 0, closest_rays, max_rays, d_hits, nullptr, nullptr},
+                                        {NNBVH_BATCH_ANY, 0, shadow_rays, max_shadow_rays, occ, nullptr, nullptr}};
+        rc = launch_fused_batches(s, w, stream, batches, 2, sizes);
+    }
     if (rc != NNBVH_OK) return rc;
     if (!hip_ok(launch_wf_enqueue_closest(d_hits, cnt, ray_queue->has_medium, d_prim_class, (long)n_prim_class, *out,
                                           max_blocks, stream),

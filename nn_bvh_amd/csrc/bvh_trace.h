@@ -48,6 +48,10 @@ struct TraceParams {
     void *bOut[kMaxFusedBatches];
     long bN[kMaxFusedBatches];
     const int32_t *bNDev[kMaxFusedBatches];  // nullable: device-resident size of batch b, clamped to [0, bN[b]]
+    // rays == nullptr (bRays[b] == nullptr): the batch is a wavefront queue, read as the SOA<Ray> slices it is
+    // (tmax == nullptr: Infinity, time == nullptr: 0) — no gather pass into nnbvh_ray records
+    nnbvh_ray_soa soa;
+    nnbvh_ray_soa bSoa[kMaxFusedBatches];
 };
 
 // bvh_layout.cpp: re-orders the baked arrays in memory (speed only; see the modes there)

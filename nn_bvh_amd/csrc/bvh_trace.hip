@@ -101,6 +101,9 @@ constexpr int kEnter = (int)0x80000002;   // INST = 2: the lane waits to enter a
 #ifndef NNBVH_FAT
 #define NNBVH_FAT 0
 #endif
+// SOA = 1 (lean instances of modes 0, 2, 3 only): a batch without nnbvh_ray records (rays == nullptr) is read as the
+// SOA<Ray> slices of a wavefront queue — no gather pass.  Its own instances: the mere presence of the second fetch
+// path in the refill trip cost the one-launch step 1.3 % (9.31 -> 9.44 ms).
 //
 // INST = 1: the scene is two-level (TransformedPrimitive leaves, cpu/primitive.cpp:112-131).  An
 // instance primitive saves the lane's ray state in LDS, transforms the ray with the reference's
@@ -117,7 +120,7 @@ constexpr int kEnter = (int)0x80000002;   // INST = 2: the lane waits to enter a
 // records and slots through 32-bit offsets from a scalar base, one primitive step per decision.
 // ALPHA = 1: the scene holds alpha-tested triangles (kPrimAlpha, cpu/primitive.cpp:57-70); compiled
 // separately so that other scenes pay nothing for the hash and the re-trace.
-template <int MODE, int W, int INST, int PATCH, int ALPHA = 0>
+template <int MODE, int W, int INST, int PATCH, int ALPHA = 0, int SOA = 0>
 __global__ __launch_bounds__(kBlockThreads, (INST ? 1 : (ALPHA ? (ALPHA == 2 ? NNBVH_MINW_ALPHA_PATCH : NNBVH_MINW_ALPHA) : ((MODE == 0 || MODE == 3) ? NNBVH_MINW_CLOSEST : NNBVH_MINW_ANY) + (PATCH ? 0 : NNBVH_LEAN_EXTRA_WAVES))))
 void trace_kernel(TraceParams p) {
     static_assert(PATCH || !INST, "two-level scenes need the ray direction");
@@ -627,8 +630,16 @@ void trace_kernel(TraceParams p) {
             }
             if (newRi >= 0) {
                 const nnbvh_ray *batchRays = MODE == 3 ? p.bRays[curBatch] : p.rays;
-                const float4 *in = reinterpret_cast<const float4 *>(batchRays) + 2 * (long)newRi;
-                const float4 r0 = in[0], r1 = in[1];
+                float4 r0, r1;
+                if (!SOA || batchRays) {
+                    const float4 *in = reinterpret_cast<const float4 *>(batchRays) + 2 * (long)newRi;
+                    r0 = in[0];
+                    r1 = in[1];
+                } else {  // a wavefront queue: SOA<Ray> slices (wavefront/workitems.soa:40-50)
+                    const nnbvh_ray_soa &q = MODE == 3 ? p.bSoa[curBatch] : p.soa;
+                    r0 = {q.ox[newRi], q.oy[newRi], q.oz[newRi], q.tmax ? q.tmax[newRi] : __builtin_inff()};
+                    r1 = {q.dx[newRi], q.dy[newRi], q.dz[newRi], q.time ? q.time[newRi] : 0.0f};
+                }
                 r.o = {r0.x, r0.y, r0.z};
                 tMax = r0.w;
                 const V3 d = {r1.x, r1.y, r1.z};
@@ -762,13 +773,13 @@ void trace_kernel(TraceParams p) {
 }
 
 // ------------------------------------------------------------------------------------
-template <int MODE, int W, int INST, int PATCH, int ALPHA = 0>
+template <int MODE, int W, int INST, int PATCH, int ALPHA = 0, int SOA = 0>
 static hipError_t launch_one(const TraceParams &p, int blocks, hipStream_t stream, int *occupancy) {
     if (occupancy) {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, trace_kernel<MODE, W, INST, PATCH, ALPHA>,
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, trace_kernel<MODE, W, INST, PATCH, ALPHA, SOA>,
                                                             kBlockThreads, 0);
     }
-    hipLaunchKernelGGL((trace_kernel<MODE, W, INST, PATCH, ALPHA>), dim3((unsigned)blocks), dim3(kBlockThreads), 0,
+    hipLaunchKernelGGL((trace_kernel<MODE, W, INST, PATCH, ALPHA, SOA>), dim3((unsigned)blocks), dim3(kBlockThreads), 0,
                        stream, p);
     return hipGetLastError();
 }
@@ -779,7 +790,11 @@ static hipError_t launch_fused(const TraceParams &p, int window, int instanced, 
     if (window != 8 || (patches & 2)) return hipErrorInvalidValue;
     if (instanced) return p.anim ? launch_one<3, 8, 2, 1>(p, blocks, stream, occupancy)
                                  : launch_one<3, 8, 1, 1>(p, blocks, stream, occupancy);
-    if (!patches && !p.hasHostPrims && p.fits32) return launch_one<3, 8, 0, 0>(p, blocks, stream, occupancy);
+    bool soa = false;
+    for (int b = 0; b < p.nBatches; ++b) soa = soa || !p.bRays[b];
+    if (!patches && !p.hasHostPrims && p.fits32)
+        return soa ? launch_one<3, 8, 0, 0, 0, 1>(p, blocks, stream, occupancy) : launch_one<3, 8, 0, 0>(p, blocks, stream, occupancy);
+    if (soa) return hipErrorInvalidValue;  // SOA batches: lean instances only (the caller gathers otherwise)
     return launch_one<3, 8, 0, 1>(p, blocks, stream, occupancy);
 }
 
@@ -801,7 +816,12 @@ static hipError_t launch_mode(const TraceParams &p, int window, int instanced, i
     }
     if (instanced) return p.anim ? launch_one<MODE, 8, 2, 1>(p, blocks, stream, occupancy)
                                  : launch_one<MODE, 8, 1, 1>(p, blocks, stream, occupancy);
-    if (!patches && !p.hasHostPrims && p.fits32 && window == 8) return launch_one<MODE, 8, 0, 0>(p, blocks, stream, occupancy);
+    const bool soa = !p.rays && !occupancy;
+    if (!patches && !p.hasHostPrims && p.fits32 && window == 8 && !instanced) {
+        if (soa && MODE != 1) return launch_one<MODE == 1 ? 0 : MODE, 8, 0, 0, 0, 1>(p, blocks, stream, occupancy);
+        if (!soa) return launch_one<MODE, 8, 0, 0>(p, blocks, stream, occupancy);
+    }
+    if (soa) return hipErrorInvalidValue;  // SOA batches: lean instances of modes 0 / 2 / 3 only
     switch (window) {
     case 4: return launch_one<MODE, 4, 0, 1>(p, blocks, stream, occupancy);
     case 8: return launch_one<MODE, 8, 0, 1>(p, blocks, stream, occupancy);
