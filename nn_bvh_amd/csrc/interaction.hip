@@ -287,7 +287,13 @@ IDEV void patch_interaction(const MeshView &m, int prim, float u, float v, F3 wo
     put(r.dndv, dndv);
 }
 
-__global__ __launch_bounds__(256) void k_triangle_interactions(
+// FULL = false: the mesh has neither bilinear patches nor an instance table — the patch interaction, the
+// instance / AnimatedPrimitive transforms and their registers are compiled out (crown: 1.00 -> see DESIGN.md §5.6)
+#ifndef NNBVH_INTR_LEAN_WAVES
+#define NNBVH_INTR_LEAN_WAVES 4
+#endif
+template <bool FULL>
+__global__ __launch_bounds__(256, FULL ? 1 : NNBVH_INTR_LEAN_WAVES) void k_triangle_interactions(
     MeshView m, const float4 *__restrict__ rays, nnbvh_ray_soa soa, const float4 *__restrict__ hits, int n,
     const int32_t *nDev, nnbvh_interaction *__restrict__ out) {
     if (nDev) {
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
             const int inst = __float_as_int(h1.w);  // 0 top level, k + 1 inside instance k
             if ((inst == 0 || (inst > 0 && inst <= m.nInstances)) && prim < m.nTris) {
                 if (m.triVerts[3 * (long)prim] >= 0) r.status = NNBVH_INTERACTION_TRIANGLE;
-                else if (m.patchVerts && m.patchVerts[4 * (long)prim] >= 0) r.status = NNBVH_INTERACTION_PATCH;
+                else if (FULL && m.patchVerts && m.patchVerts[4 * (long)prim] >= 0) r.status = NNBVH_INTERACTION_PATCH;
             }
         }
         if (r.status != NNBVH_INTERACTION_TRIANGLE && r.status != NNBVH_INTERACTION_PATCH) {
@@ -325,9 +331,9 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
             wo = {-soa.dx[i], -soa.dy[i], -soa.dz[i]};
             time = soa.time ? soa.time[i] : 0.0f;
         }
-        const int instIdx = __float_as_int(h1.w) - 1;
+        const int instIdx = FULL ? __float_as_int(h1.w) - 1 : -1;
         nnbvh_instance xf;  // the instance's transform as this ray sees it
-        if (instIdx >= 0) {
+        if (FULL && instIdx >= 0) {
             xf = m.instances[instIdx];
             if (m.anim && m.anim[(long)kAnimStride * instIdx + 74] != 0.0f) {
                 // AnimatedPrimitive::Intersect (cpu/primitive.cpp:143-153): renderFromPrimitive.Interpolate(r.time),
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
                            mi[8] * d.x + mi[9] * d.y + mi[10] * d.z};
             wo = neg(di);
         }
-        if (r.status == NNBVH_INTERACTION_PATCH) {
+        if (FULL && r.status == NNBVH_INTERACTION_PATCH) {
             patch_interaction(m, prim, h0.z, h0.w, wo, time, r);
             if (instIdx >= 0) transform_interaction(xf, r);
             out[i] = r;
@@ -470,7 +476,16 @@ __global__ __launch_bounds__(256) void k_triangle_interactions(
         r.dndus[0] = dndu.x, r.dndus[1] = dndu.y, r.dndus[2] = dndu.z;
         r.dndvs[0] = dndv.x, r.dndvs[1] = dndv.y, r.dndvs[2] = dndv.z;
         if (instIdx >= 0) transform_interaction(xf, r);
+#ifdef NNBVH_INTR_PROBE_NOWRITE  // tools only: what the 192-B record stores cost (the record is folded into 16 B)
+        {
+            const float *f = reinterpret_cast<const float *>(&r);
+            float4 acc = {0, 0, 0, 0};
+            for (int k = 0; k < 48; k += 4) acc = {acc.x + f[k], acc.y + f[k + 1], acc.z + f[k + 2], acc.w + f[k + 3]};
+            reinterpret_cast<float4 *>(out + i)[11] = acc;
+        }
+#else
         out[i] = r;
+#endif
     }
 }
 
@@ -484,8 +499,12 @@ hipError_t launch_triangle_interactions(const ShadingMeshDevice &m, const void *
     if (soa) s = *soa;
     int blocks = (n + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks < maxBlocks ? blocks : maxBlocks);
-    hipLaunchKernelGGL(k_triangle_interactions, dim3(blocks), dim3(256), 0, stream, v, (const float4 *)rays, s,
-                       (const float4 *)hits, n, nDev, (nnbvh_interaction *)out);
+    if (m.patchVerts || m.instances)
+        hipLaunchKernelGGL(k_triangle_interactions<true>, dim3(blocks), dim3(256), 0, stream, v, (const float4 *)rays, s,
+                           (const float4 *)hits, n, nDev, (nnbvh_interaction *)out);
+    else
+        hipLaunchKernelGGL(k_triangle_interactions<false>, dim3(blocks), dim3(256), 0, stream, v, (const float4 *)rays, s,
+                           (const float4 *)hits, n, nDev, (nnbvh_interaction *)out);
     return hipGetLastError();
 }
 
