@@ -77,8 +77,8 @@ typedef struct nnbvh_linear_node {
 #define NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH 6  /* ... of a mesh WITH per-vertex shading normals: the ray re-traced
                                        after a rejected hit is offset along FaceForward(n, ns) (shapes.h:
                                        939-951, interaction.h:194-200); needs the scene's vertex normals
-                                       (nnbvh_scene_create_with_normals).  BVH scenes; inside a kd-tree
-                                       such primitives stay NNBVH_PRIM_HOST */
+                                       (nnbvh_scene_create_with_normals; kd-trees:
+                                       nnbvh_kd_scene_create_with_attributes) */
 #define NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED 7
 #define NNBVH_PRIM_ALPHA_PATCH 8   /* BilinearPatch behind a GeometricPrimitive with a CONSTANT alpha (v[0..3] are the
                                        patch's vertices: the alpha comes from the per-primitive array of
@@ -86,8 +86,7 @@ typedef struct nnbvh_linear_node {
                                        ray re-traced off its own surface; the recursion of cpu/primitive.cpp:63-69 is
                                        followed for up to three re-traces, beyond which the record is void
                                        (needs-host).  For patch meshes WITHOUT (u, v) coordinates (with them: kinds
-                                       12 .. 15).  BVH scenes (inside a kd-tree such primitives stay
-                                       NNBVH_PRIM_HOST) */
+                                       12 .. 15) */
 #define NNBVH_PRIM_ALPHA_PATCH_FLIPPED 9         /* same, mesh->reverseOrientation ^ transformSwapsHandedness */
 #define NNBVH_PRIM_ALPHA_PATCH_SMOOTH 10         /* ... of a mesh WITH per-vertex normals (BilinearPatchMesh::n as
                                                      the mesh stores them, util/mesh.cpp:216-223) */
@@ -586,6 +585,14 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
                                       int n_indices, const nnbvh_prim *prims, int n_prims,
                                       const float *verts, int n_verts, const float bounds_min_max[6],
                                       int device);
+/* ... with the attributes the alpha-tested kinds read: normals and uvs per vertex, prim_alpha per entry of `prims`
+ * (kd primitives are in the caller's order).  A kind whose arrays are missing stays the host's (record void), as
+ * every such kind does through nnbvh_kd_scene_create. */
+nnbvh_kd_scene *nnbvh_kd_scene_create_with_attributes(const nnbvh_kd_node *nodes, int n_nodes,
+                                                      const int32_t *prim_indices, int n_indices,
+                                                      const nnbvh_prim *prims, int n_prims, const float *verts,
+                                                      int n_verts, const float bounds_min_max[6], const float *normals,
+                                                      const float *uvs, const float *prim_alpha, int device);
 void nnbvh_kd_scene_destroy(nnbvh_kd_scene *s);
 /* host buffers (synchronous) */
 int nnbvh_kd_intersect_closest(nnbvh_kd_scene *s, const nnbvh_ray *rays, int64_t n, nnbvh_hit *hits);

@@ -60,7 +60,7 @@ EXPORTS = [
     "nnbvh_film_unpack_pixels_device", "nnbvh_kd_build_create", "nnbvh_kd_build_create_gpu",
     "nnbvh_kd_build_create_stable", "nnbvh_kd_build_timing", "nnbvh_kd_build_nodes",
     "nnbvh_kd_build_prim_indices", "nnbvh_kd_build_bounds", "nnbvh_kd_build_depth", "nnbvh_kd_build_destroy",
-    "nnbvh_kd_scene_create", "nnbvh_kd_scene_destroy", "nnbvh_kd_intersect_closest", "nnbvh_kd_intersect_any",
+    "nnbvh_kd_scene_create", "nnbvh_kd_scene_create_with_attributes", "nnbvh_kd_scene_destroy", "nnbvh_kd_intersect_closest", "nnbvh_kd_intersect_any",
     "nnbvh_kd_intersect_closest_device", "nnbvh_kd_intersect_any_device",
     "nnbvh_wavefront_intersect_shadow_tr", "nnbvh_wavefront_intersect_one_random",
     "nnbvh_scene_create_instanced_animated",
@@ -205,6 +205,8 @@ def lib():
     L.nnbvh_kd_build_destroy.argtypes = [vp]
     L.nnbvh_kd_scene_create.restype = vp
     L.nnbvh_kd_scene_create.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32]
+    L.nnbvh_kd_scene_create_with_attributes.restype = vp
+    L.nnbvh_kd_scene_create_with_attributes.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32]
     L.nnbvh_kd_scene_destroy.restype = None
     L.nnbvh_kd_scene_destroy.argtypes = [vp]
     L.nnbvh_kd_intersect_closest.restype = i32

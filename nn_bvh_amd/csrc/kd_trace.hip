@@ -56,6 +56,8 @@ struct KdParams {
     int primWeight, refillWeight, nodeRepeat;
     int hasHostPrims;
     float4 *spill;                // [kMaxStack][grid threads] overflow of the LDS window
+    const float4 *extras;         // ATTR instances: 6 slots per primitive {n0} {n1} {n2} {n3} {uv00, uv10} {uv01, uv11}
+                                  // (per-vertex normals / uvs of the alpha-tested kinds that read them), else null
 };
 
 // util/vecmath.h:1547-1571 with invRayDir = 1 / d[i] taken from the ray's precomputed reciprocals
@@ -90,7 +92,9 @@ DEV bool kd_root_interval(const float bmin[3], const float bmax[3], V3 o, V3 inv
 // W: entries per lane of the LDS window of the to-visit stack.
 // O32: nodes, primitive records and primitiveIndices are each below 4 GiB and are fetched through 32-bit
 // byte offsets from a scalar base (no 64-bit shift / add per fetch).
-template <int MODE, int PATCH, int W, int O32>
+// ATTR = 1 (with PATCH = 1): the scene holds alpha-tested triangles of smooth meshes or alpha-tested bilinear patches,
+// whose re-trace reads per-vertex attributes from p.extras (bvh_trace.hip's ALPHA = 1 smooth / ALPHA = 2 code)
+template <int MODE, int PATCH, int W, int O32, int ATTR = 0>
 __global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdParams p) {
     auto at = [](const auto *base, int index) {  // &base[index]
         using T = decltype(base);
@@ -268,8 +272,16 @@ __global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdPar
                                 if (u > a) {
                                     hit = false;
                                     RayState rn = r;
-                                    rn.o = alpha_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z},
-                                                                x0, x1, x2, (flags & kPrimFlipN) != 0, d);
+                                    if (ATTR && (flags & kPrimSmooth)) {  // FaceForward(n, ns): shapes.h:939-951
+                                        const float4 *ex = p.extras + 6 * (long)leafIdx;
+                                        const float4 m0 = ex[0], m1 = ex[1], m2 = ex[2];
+                                        rn.o = alpha_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z},
+                                                                    x0, x1, x2, (flags & kPrimFlipN) != 0, d, true,
+                                                                    {m0.x, m0.y, m0.z}, {m1.x, m1.y, m1.z}, {m2.x, m2.y, m2.z});
+                                    } else {
+                                        rn.o = alpha_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z},
+                                                                    x0, x1, x2, (flags & kPrimFlipN) != 0, d);
+                                    }
                                     tests += 1;  // Triangle::Intersect counts the re-test too
                                     float y0, y1, y2, tn;
                                     if (triangle_test(rn, rayTMax - th, (flags & kPrimDegenerate) != 0, {s0.x, s0.y, s0.z},
@@ -281,8 +293,45 @@ __global__ __launch_bounds__(kKdBlock, PATCH ? 1 : 2) void kd_trace_kernel(KdPar
                     } else {
                         const float4 s3 = rec[3];
                         x2 = 0.0f;
-                        hit = patch_test(r, d, rayTMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
-                                         {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
+                        if constexpr (ATTR != 0) {
+                            // GeometricPrimitive::Intersect around a BilinearPatch: the recursion of cpu/primitive.cpp:
+                            // 63-69 followed for up to three re-traces, as in bvh_trace.hip (ALPHA = 2)
+                            constexpr int kAlphaPatchDepth = 3;
+                            const float a = (flags & kPrimAlpha) ? s2.w : 1.0f;
+                            RayState rn = r;
+                            float tm = rayTMax, t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+                            int k = 0;
+                            for (;;) {
+                                hit = patch_test(rn, d, tm, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z},
+                                                 {s3.x, s3.y, s3.z}, x0, x1, th);
+                                if (!hit || !(a < 1)) break;
+                                const float u = (a <= 0) ? 1.f : hash_float_6f(rn.o, d);
+                                if (!(u > a)) break;
+                                if (k == kAlphaPatchDepth) {
+                                    hit = false;
+                                    cold[kColdHost][lane] = 1.0f;
+                                    break;
+                                }
+                                if (k == 0) t0 = th;
+                                else if (k == 1) t1 = th;
+                                else t2 = th;
+                                ++k;
+                                rn.o = patch_retrace_origin({s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z}, {s2.x, s2.y, s2.z},
+                                                            {s3.x, s3.y, s3.z}, x0, x1, (flags & kPrimFlipN) != 0, d,
+                                                            (flags & kPrimSmooth) != 0, (flags & kPrimUV) != 0,
+                                                            p.extras + 6 * (long)leafIdx, 4);
+                                tm = tm - th;
+                                tests += 1;
+                            }
+                            if (hit && k > 0) {
+                                if (k == 3) th = th + t2;
+                                if (k >= 2) th = th + t1;
+                                th = th + t0;
+                            }
+                        } else {
+                            hit = patch_test(r, d, rayTMax, {s0.x, s0.y, s0.z}, {s1.x, s1.y, s1.z},
+                                             {s2.x, s2.y, s2.z}, {s3.x, s3.y, s3.z}, x0, x1, th);
+                        }
                     }
                     if (hit) {
                         if (MODE == 0) {
@@ -437,6 +486,7 @@ struct nnbvh_kd_scene {
     uint2 *d_nodes = nullptr;
     int32_t *d_indices = nullptr;
     float4 *d_prims = nullptr;
+    float4 *d_extras = nullptr;  // 6 slots per primitive, scenes with attribute-reading alpha kinds only
     int blocks_per_cu[2] = {0, 0};
     std::mutex mu;
     std::map<hipStream_t, KdWorkspace> workspaces;
@@ -490,7 +540,12 @@ static int kd_launch(nnbvh_kd_scene *s, int mode, const void *d_rays, int64_t n,
         kd_trace_kernel<0, 0, kKdWLean, 0>, kd_trace_kernel<1, 0, kKdWLean, 0>, kd_trace_kernel<0, 1, kKdW, 0>,
         kd_trace_kernel<1, 1, kKdW, 0>,     kd_trace_kernel<0, 0, kKdWLean, 1>, kd_trace_kernel<1, 0, kKdWLean, 1>,
         kd_trace_kernel<0, 1, kKdW, 1>,     kd_trace_kernel<1, 1, kKdW, 1>};
-    void (*const kernel)(KdParams) = kernels[mode + 2 * s->has_patches + 4 * s->fits32];
+    // ... and the attribute-reading forms of the PATCH instances
+    void (*const attr_kernels[4])(KdParams) = {kd_trace_kernel<0, 1, kKdW, 0, 1>, kd_trace_kernel<1, 1, kKdW, 0, 1>,
+                                               kd_trace_kernel<0, 1, kKdW, 1, 1>, kd_trace_kernel<1, 1, kKdW, 1, 1>};
+    p.extras = s->d_extras;
+    void (*const kernel)(KdParams) = s->d_extras ? attr_kernels[mode + 2 * s->fits32]
+                                                 : kernels[mode + 2 * s->has_patches + 4 * s->fits32];
     if (s->blocks_per_cu[mode] == 0) {
         int occ = 0;
         const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kKdBlock, 0);
@@ -509,6 +564,15 @@ extern "C" {
 nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, const int32_t *prim_indices,
                                       int n_indices, const nnbvh_prim *prims, int n_prims, const float *verts,
                                       int n_verts, const float bounds_min_max[6], int device) {
+    return nnbvh_kd_scene_create_with_attributes(nodes, n_nodes, prim_indices, n_indices, prims, n_prims, verts, n_verts,
+                                                 bounds_min_max, nullptr, nullptr, nullptr, device);
+}
+
+nnbvh_kd_scene *nnbvh_kd_scene_create_with_attributes(const nnbvh_kd_node *nodes, int n_nodes,
+                                                      const int32_t *prim_indices, int n_indices,
+                                                      const nnbvh_prim *prims, int n_prims, const float *verts,
+                                                      int n_verts, const float bounds_min_max[6], const float *normals,
+                                                      const float *uvs, const float *prim_alpha, int device) {
     if (!nodes || n_nodes <= 0 || n_indices < 0 || (n_indices > 0 && !prim_indices) || !prims || n_prims <= 0 ||
         !verts || n_verts <= 0 || !bounds_min_max) {
         set_error("kd_scene_create: null or empty argument");
@@ -578,19 +642,41 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
     // ---- primitive records: 4 slots per primitive in the caller's order --------------------------
     std::vector<float> rec((size_t)n_prims * 16, 0.0f);
     bool has_host = false, has_patch = false;
+    // the alpha-tested kinds that read per-vertex attributes: on the device when the caller gave what they read
+    // (6 more slots per primitive in a second array), else the host's as before
+    auto on_device = [&](int kind) {
+        if (is_smooth_alpha_kind(kind)) return normals != nullptr;
+        if (is_alpha_patch_kind(kind))
+            return prim_alpha && (!is_smooth_alpha_patch_kind(kind) || normals) && (!is_uv_alpha_patch_kind(kind) || uvs);
+        return false;
+    };
+    bool any_attr = false;
+    for (int k = 0; k < n_prims && !any_attr; ++k) any_attr = on_device(prims[k].kind);
+    std::vector<float> extras(any_attr ? (size_t)n_prims * 24 : 0, 0.0f);
     for (int k = 0; k < n_prims; ++k) {
         const nnbvh_prim &pr = prims[k];
         float *s = &rec[(size_t)k * 16];
         uint32_t flags = 0;
         std::memcpy(&s[3], &pr.id, 4);
-        if (pr.kind == NNBVH_PRIM_HOST || is_smooth_alpha_kind(pr.kind) || is_alpha_patch_kind(pr.kind)) {
-            // (alpha-tested triangles of smooth meshes and alpha-tested patches: their re-trace needs the vertex normals /
-            // the per-primitive alpha, which the 4-slot kd primitive record has no room for — inside a kd-tree they are
-            // the host's)
+        const bool attr = on_device(pr.kind);
+        if (pr.kind == NNBVH_PRIM_HOST || ((is_smooth_alpha_kind(pr.kind) || is_alpha_patch_kind(pr.kind)) && !attr)) {
+            // (alpha-tested triangles of smooth meshes and alpha-tested patches without the arrays they read: the host's)
             flags |= kPrimHost;
             has_host = true;
-        } else if (is_triangle_kind(pr.kind) || pr.kind == NNBVH_PRIM_BILINEAR_PATCH) {
+        } else if (is_triangle_kind(pr.kind) || pr.kind == NNBVH_PRIM_BILINEAR_PATCH || is_alpha_patch_kind(pr.kind)) {
             const int nv = is_triangle_kind(pr.kind) ? 3 : 4;
+            if (attr) {
+                float *ex = &extras[(size_t)k * 24];
+                const bool smooth = is_smooth_alpha_kind(pr.kind) || is_smooth_alpha_patch_kind(pr.kind);
+                for (int j = 0; j < nv && smooth; ++j)
+                    if (pr.v[j] >= 0 && pr.v[j] < n_verts) std::memcpy(&ex[4 * j], normals + 3 * (size_t)pr.v[j], 12);
+                for (int j = 0; j < 4 && is_uv_alpha_patch_kind(pr.kind); ++j)
+                    if (pr.v[j] >= 0 && pr.v[j] < n_verts) std::memcpy(&ex[16 + 2 * j], uvs + 2 * (size_t)pr.v[j], 8);
+                flags |= kPrimAlpha | (smooth ? kPrimSmooth : 0u) | (is_uv_alpha_patch_kind(pr.kind) ? kPrimUV : 0u);
+                if (pr.kind == NNBVH_PRIM_ALPHA_TRIANGLE_SMOOTH_FLIPPED || is_flipped_alpha_patch_kind(pr.kind)) flags |= kPrimFlipN;
+                has_host = true;   // a re-trace chain that does not end voids the ray
+                has_patch = true;  // the alpha test hashes the ray direction
+            }
             if (pr.kind == NNBVH_PRIM_ALPHA_TRIANGLE || pr.kind == NNBVH_PRIM_ALPHA_TRIANGLE_FLIPPED) {
                 // the alpha value rides in v[3] (bit pattern) and goes to slot 2's w, as in the BVH scenes;
                 // a re-trace that hits voids the ray like a host primitive, and the test needs the ray
@@ -607,7 +693,10 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
                 std::memcpy(&s[4 * j], verts + 3 * (size_t)pr.v[j], 12);
             }
             std::memcpy(&s[3], &pr.id, 4);
-            if (flags & kPrimAlpha) std::memcpy(&s[11], &pr.v[3], 4);
+            if (flags & kPrimAlpha) {
+                if (is_alpha_patch_kind(pr.kind)) s[11] = prim_alpha[k];  // a patch needs all four v[]
+                else std::memcpy(&s[11], &pr.v[3], 4);
+            }
             if (nv == 4) {
                 flags |= kPrimPatch;
                 has_patch = true;
@@ -645,6 +734,9 @@ nnbvh_kd_scene *nnbvh_kd_scene_create(const nnbvh_kd_node *nodes, int n_nodes, c
     if (ok && n_indices > 0)
         ok = kd_hip_ok(hipMemcpy(s->d_indices, prim_indices, (size_t)n_indices * 4, hipMemcpyHostToDevice),
                        "upload kd indices");
+    if (ok && any_attr)
+        ok = kd_hip_ok(hipMalloc((void **)&s->d_extras, extras.size() * 4), "hipMalloc(kd attributes)") &&
+             kd_hip_ok(hipMemcpy(s->d_extras, extras.data(), extras.size() * 4, hipMemcpyHostToDevice), "upload kd attributes");
     if (!ok) {
         nnbvh_kd_scene_destroy(s);
         return nullptr;
@@ -663,6 +755,7 @@ void nnbvh_kd_scene_destroy(nnbvh_kd_scene *s) {
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_indices) (void)hipFree(s->d_indices);
     if (s->d_prims) (void)hipFree(s->d_prims);
+    if (s->d_extras) (void)hipFree(s->d_extras);
     delete s;
 }
 

@@ -160,8 +160,9 @@ DEV V3 lerp_v3(float t, V3 a, V3 b) {  // (1 - t) * a + t * b: vecmath.h:410-412
 // `extra` = the slots after the patch's four: {n00} {n10} {n01} {n11} if smooth, then {uv00, uv10} {uv01, uv11} if
 // hasUV; they are read where they are needed (the (u, v) pair before the normal, the normals last) so that the
 // patch's 20 attribute words are never live together
+// uvAt: slot of the (u, v) pair in `extra` (default: right after the normals that are there)
 DEV V3 patch_retrace_origin(V3 p00, V3 p10, V3 p01, V3 p11, float u, float v, bool flip, V3 d, bool smooth, bool hasUV,
-                            const float4 *extra) {
+                            const float4 *extra, int uvAt = -1) {
     const V3 a = lerp_v3(v, p00, p01), b = lerp_v3(v, p10, p11);
     const V3 ph = lerp_v3(u, a, b);
     V3 dpdu = sub(b, a);
@@ -175,7 +176,8 @@ DEV V3 patch_retrace_origin(V3 p00, V3 p10, V3 p01, V3 p11, float u, float v, bo
     const V3 hi = {pe.x == 0 ? ph.x : next_up(ph.x + pe.x), pe.y == 0 ? ph.y : next_up(ph.y + pe.y),
                    pe.z == 0 ? ph.z : next_up(ph.z + pe.z)};
     if (hasUV) {
-        const float4 uvA = extra[smooth ? 4 : 0], uvB = extra[smooth ? 5 : 1];
+        if (uvAt < 0) uvAt = smooth ? 4 : 0;
+        const float4 uvA = extra[uvAt], uvB = extra[uvAt + 1];
         const float sv = 1 - v, su = 1 - u;
         const float s0x = sv * uvA.x + v * uvB.x, s0y = sv * uvA.y + v * uvB.y;  // Lerp(v, uv00, uv01)
         const float s1x = sv * uvA.z + v * uvB.z, s1y = sv * uvA.w + v * uvB.w;  // Lerp(v, uv10, uv11)

@@ -56,22 +56,29 @@ class KdTreeAggregate:
         self.bounds = bounds
 
     @classmethod
-    def from_tree(cls, nodes, prim_indices, prims, verts, bounds, device=0):
+    def from_tree(cls, nodes, prim_indices, prims, verts, bounds, device=0, normals=None, uvs=None, prim_alpha=None):
+        """normals / uvs (per vertex) and prim_alpha (per entry of prims): what the alpha-tested kinds of smooth meshes
+        and the alpha-tested patches read; without them such primitives are the host's (void records)."""
         nodes = np.ascontiguousarray(nodes, KD_NODE_DTYPE)
         idx = np.ascontiguousarray(prim_indices, np.int32)
         prims = np.ascontiguousarray(prims, PRIM_DTYPE)
-        verts = np.ascontiguousarray(verts, np.float32)
+        verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         bounds = np.ascontiguousarray(bounds, np.float32)
-        h = _lib.lib().nnbvh_kd_scene_create(ptr(nodes), len(nodes), ptr(idx) if len(idx) else None, len(idx),
-                                             ptr(prims), len(prims), ptr(verts), len(verts), ptr(bounds), device)
+        nrm = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(len(verts), 3)
+        uv = None if uvs is None else np.ascontiguousarray(uvs, np.float32).reshape(len(verts), 2)
+        pa = None if prim_alpha is None else np.ascontiguousarray(prim_alpha, np.float32).reshape(len(prims))
+        opt = lambda a: ptr(a) if a is not None else None  # noqa: E731
+        h = _lib.lib().nnbvh_kd_scene_create_with_attributes(
+            ptr(nodes), len(nodes), ptr(idx) if len(idx) else None, len(idx), ptr(prims), len(prims), ptr(verts),
+            len(verts), ptr(bounds), opt(nrm), opt(uv), opt(pa), device)
         if not h:
             raise _lib.NNBVHError(f"nnbvh_kd_scene_create failed: {_lib.last_error()}")
         return cls(h, bounds)
 
     @classmethod
-    def build(cls, prims, verts, device=0, **kw):
+    def build(cls, prims, verts, device=0, normals=None, uvs=None, prim_alpha=None, **kw):
         t = build_kd_tree(prims, verts, **kw)
-        return cls.from_tree(t.nodes, t.prim_indices, prims, verts, t.bounds, device)
+        return cls.from_tree(t.nodes, t.prim_indices, prims, verts, t.bounds, device, normals, uvs, prim_alpha)
 
     def close(self):
         if self._h:

@@ -1874,6 +1874,7 @@ static void kd_run(kd_job base, int64_t n, int nthreads) {
 void orc_kd_intersect_closest(const orc_kd_node *nodes, const int32_t *prim_indices, const orc_prim *prims,
                               const float *verts, const float bounds[6], const orc_ray *rays, int64_t n,
                               orc_hit *hits, int nthreads) {
+    g_prim_alpha_base = prims; /* alpha-tested patches index orc_set_prim_alpha's array by position */
     kd_job j;
     memset(&j, 0, sizeof j);
     j.nodes = nodes;
@@ -1889,6 +1890,7 @@ void orc_kd_intersect_closest(const orc_kd_node *nodes, const int32_t *prim_indi
 void orc_kd_intersect_any(const orc_kd_node *nodes, const int32_t *prim_indices, const orc_prim *prims,
                           const float *verts, const float bounds[6], const orc_ray *rays, int64_t n,
                           uint8_t *occluded, int32_t *nodes_visited, int32_t *prim_tests, int nthreads) {
+    g_prim_alpha_base = prims; /* alpha-tested patches index orc_set_prim_alpha's array by position */
     kd_job j;
     memset(&j, 0, sizeof j);
     j.nodes = nodes;

@@ -154,11 +154,13 @@ def compare(agg, tree, verts, rays):
     return sorted(bad), exp
 
 
-def compare_kd(verts, prims, rays, max_prims):
-    """The same rays through KdTreeAggregate (kd_trace.hip) against the oracle's kd traversal."""
+def compare_kd(verts, prims, rays, max_prims, normals=None, uvs=None, prim_alpha=None):
+    """The same rays through KdTreeAggregate (kd_trace.hip) against the oracle's kd traversal (kd primitives are in
+    the caller's order: prim_alpha as drawn; the oracle's attribute arrays are set by the caller)."""
     from nn_bvh_amd.kdtree import KdTreeAggregate, build_kd_tree
     tree = build_kd_tree(prims, verts, max_prims=max_prims)
-    agg = KdTreeAggregate.from_tree(tree.nodes, tree.prim_indices, prims, verts, tree.bounds)
+    agg = KdTreeAggregate.from_tree(tree.nodes, tree.prim_indices, prims, verts, tree.bounds, normals=normals, uvs=uvs,
+                                    prim_alpha=prim_alpha)
     exp = ob.kd_closest(tree.nodes, tree.prim_indices, prims, verts, tree.bounds, rays, 8)
     got = agg.Intersect(rays)
     bad = set()
@@ -236,8 +238,11 @@ def main():
             agg.set_option("stack_window", int(rng.choice([4, 16])))
         rays = draw_rays(rng, verts, prims, args.rays)
         bad, exp = compare(agg, tree, verts, rays)
-        if args.kd and normals is None and prim_alpha is None:  # (inside a kd-tree the smooth kinds and the alpha patches are host-only primitives)
-            kbad = compare_kd(verts, prims, rays, max_prims=int(rng.choice([1, 4])))
+        if args.kd:
+            ob.set_prim_alpha(prim_alpha)  # kd primitives are in the caller's order
+            kbad = compare_kd(verts, prims, rays, max_prims=int(rng.choice([1, 4])), normals=normals, uvs=uvs,
+                              prim_alpha=prim_alpha)
+            ob.set_prim_alpha(a_ord)
             if kbad:
                 print(f"KD MISMATCH seed {seed}: {len(kbad)} rays, first {kbad[:5]}", flush=True)
                 bad = bad + kbad

@@ -222,6 +222,50 @@ def test_device_kd_traversal_with_alpha_tested_triangles():
 
 
 @pytest.mark.gpu
+def test_device_kd_traversal_with_attribute_reading_alpha_kinds():
+    """nnbvh_kd_scene_create_with_attributes: alpha-tested triangles of smooth meshes (kinds 6 / 7) and alpha-tested
+    bilinear patches (kinds 8 .. 15, recursion after a rejected hit included) inside a KdTreeAggregate — once per leaf
+    the primitive overlaps, like every kd primitive.  Without the arrays they read such primitives void the ray."""
+    from test_alpha import alpha_patch_scene, patch_uvs
+    verts, prims, normals, alpha, kinds = alpha_patch_scene(43, 1500, 2500)
+    rng = np.random.default_rng(4)
+    prims = prims.copy()
+    smooth = ((kinds == 4) | (kinds == 5)) & (rng.random(len(prims)) < 0.5)
+    prims["kind"] = np.where(smooth, kinds + 2, kinds)
+    kinds = prims["kind"].copy()
+    uvs = patch_uvs(verts)
+    tree = build_kd_tree(prims, verts, max_prims=2)
+    rays = np.concatenate([scene.random_rays(40000, verts.min(0) - 1, verts.max(0) + 1, 21),
+                           scene.random_rays(8000, verts.min(0), verts.max(0), 22, tmax=0.6)])
+    agg = KdTreeAggregate.from_tree(tree.nodes, tree.prim_indices, prims, verts, tree.bounds, normals=normals, uvs=uvs,
+                                    prim_alpha=alpha)
+    got = agg.Intersect(rays)
+    occ, vis, tst = agg.IntersectP(rays, counts=True)
+    try:
+        ob.set_vertex_normals(normals)
+        ob.set_vertex_uvs(uvs)
+        ob.set_prim_alpha(alpha)
+        exp = ob.kd_closest(tree.nodes, tree.prim_indices, prims, verts, tree.bounds, rays, 4)
+        eo, ev, et = ob.kd_any_hit(tree.nodes, tree.prim_indices, prims, verts, tree.bounds, rays, 4)
+    finally:
+        ob.set_vertex_normals(None)
+        ob.set_vertex_uvs(None)
+        ob.set_prim_alpha(None)
+    assert got.tobytes() == exp.tobytes()
+    assert np.array_equal(occ, eo) and np.array_equal(vis, ev) and np.array_equal(tst, et)
+    assert np.array_equal(agg.IntersectP(rays), eo)
+    hit_kind = kinds[np.maximum(exp["prim"], 0)]
+    for k in (6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
+        assert ((hit_kind == k) & (exp["prim"] >= 0)).sum() > 50, k
+    agg.close()
+    # without the arrays: the host's
+    plain = KdTreeAggregate.from_tree(tree.nodes, tree.prim_indices, prims, verts, tree.bounds)
+    void = plain.Intersect(rays[:5000])["instance"] == -1
+    assert void.sum() > 500
+    plain.close()
+
+
+@pytest.mark.gpu
 def test_device_kd_traversal_mesh_host_prims_and_deep_stack():
     # connected mesh: shared edges / vertices, ties
     verts, prims = ss.grid_mesh(64, 3)
