@@ -309,7 +309,9 @@ class HipKdTreeAggregate {
   public:
     HipKdTreeAggregate(const std::vector<nnbvh_prim> &prims, const std::vector<float> &verts,
                        int isectCost = 5, int traversalCost = 1, float emptyBonus = 0.5f, int maxPrims = 1,
-                       int maxDepth = -1, int device = 0, const std::vector<float> *primBounds = nullptr) {
+                       int maxDepth = -1, int device = 0, const std::vector<float> *primBounds = nullptr,
+                       const std::vector<float> *normals = nullptr, const std::vector<float> *uvs = nullptr,
+                       const std::vector<float> *primAlpha = nullptr) {
         nnbvh_kd_build *b = nnbvh_kd_build_create(prims.data(), (int)prims.size(), verts.data(),
                                                   (int)(verts.size() / 3), primBounds ? primBounds->data() : nullptr,
                                                   isectCost, traversalCost, emptyBonus, maxPrims, maxDepth);
@@ -321,18 +323,22 @@ class HipKdTreeAggregate {
         const nnbvh_kd_node *nodes = nnbvh_kd_build_nodes(b, &nNodes);
         const int32_t *idx = nnbvh_kd_build_prim_indices(b, &nIdx);
         nnbvh_kd_build_bounds(b, bounds_);
-        scene_ = nnbvh_kd_scene_create(nodes, nNodes, idx, nIdx, prims.data(), (int)prims.size(), verts.data(),
-                                       (int)(verts.size() / 3), bounds_, device);
+        // (kd primitives stay in the caller's order: the attribute arrays pass through as they are)
+        scene_ = nnbvh_kd_scene_create_with_attributes(nodes, nNodes, idx, nIdx, prims.data(), (int)prims.size(),
+                                                       verts.data(), (int)(verts.size() / 3), bounds_,
+                                                       normals ? normals->data() : nullptr, uvs ? uvs->data() : nullptr,
+                                                       primAlpha ? primAlpha->data() : nullptr, device);
         nnbvh_kd_build_destroy(b);
         if (!scene_) HipBVHAggregate::fatal("HipKdTreeAggregate: scene_create");
     }
     // from a tree pbrt itself built: KdTreeAggregate::nodes, primitiveIndices, primitives, bounds
     HipKdTreeAggregate(const nnbvh_kd_node *nodes, int nNodes, const int32_t *primIndices, int nIndices,
                        const nnbvh_prim *prims, int nPrims, const float *verts, int nVerts,
-                       const float boundsMinMax[6], int device = 0) {
+                       const float boundsMinMax[6], int device = 0, const float *normals = nullptr,
+                       const float *uvs = nullptr, const float *primAlpha = nullptr) {
         for (int k = 0; k < 6; ++k) bounds_[k] = boundsMinMax[k];
-        scene_ = nnbvh_kd_scene_create(nodes, nNodes, primIndices, nIndices, prims, nPrims, verts, nVerts,
-                                       boundsMinMax, device);
+        scene_ = nnbvh_kd_scene_create_with_attributes(nodes, nNodes, primIndices, nIndices, prims, nPrims, verts, nVerts,
+                                                       boundsMinMax, normals, uvs, primAlpha, device);
         if (!scene_) HipBVHAggregate::fatal("HipKdTreeAggregate: scene_create");
     }
     HipKdTreeAggregate(const HipKdTreeAggregate &) = delete;
