@@ -230,6 +230,56 @@ def test_gpu_closest_and_shadow_in_one_launch(sizes):
 
 
 @pytest.mark.gpu
+def test_gpu_wavefront_iteration_is_hip_graph_capturable():
+    """One depth of the wavefront loop — queue resets, the shadow queue + the next depth's ray queue in one launch, the
+    enqueue and radiance kernels — captured in a hipGraph and replayed: the calls only enqueue kernels on the caller's
+    stream once its workspace exists (no gather pass, no allocation)."""
+    import torch
+    from nn_bvh_amd.wavefront import RayQueue, WorkQueue
+    max_rays, max_shadow, n_pixels = 6000, 5000, 8000
+    verts, prims, tree, agg, rays, WavefrontAggregate = _setup(61, max_rays)
+    srays = scene.random_rays(max_shadow, verts.min(0) - 3, verts.max(0) + 3, 78)
+    srays["tmax"] = np.float32(1 - 1e-4)
+    srays["d"] *= np.float32(12.0)
+    Ld, r_u, r_l, px, L = shadow_inputs(max_shadow, n_pixels, 9)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    rq, sq = RayQueue.from_records(rays, dev), RayQueue.from_records(srays, dev, shadow=True)
+    wf = WavefrontAggregate(agg)
+    queues = {k: WorkQueue(max_rays, dev) for k in QUEUES}
+    hits_t = torch.zeros((max_rays, 32), dtype=torch.uint8, device=dev)
+    Ld_t, ru_t, rl_t, px_t, L_t = t(Ld), t(r_u), t(r_l), t(px), t(L)
+    L0 = L_t.clone()
+    side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+
+    def iteration():
+        for q in queues.values():
+            q.Reset()
+        wf.IntersectClosestAndShadow(max_rays, rq, max_shadow, sq, Ld_t, ru_t, rl_t, px_t, L_t, hits=hits_t, **queues)
+
+    with torch.cuda.stream(side):
+        iteration()  # warm-up: creates this stream's workspace (allocation is not capturable)
+    torch.cuda.synchronize()
+    eager_hits, eager_L = hits_t.clone(), L_t.clone()
+    eager_sizes = {k: q.Size() for k, q in queues.items()}
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        iteration()
+    for _ in range(2):
+        hits_t.zero_()
+        L_t.copy_(L0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(hits_t, eager_hits) and torch.equal(L_t, eager_L)
+        assert {k: q.Size() for k, q in queues.items()} == eager_sizes
+    exp = ob.closest(tree.nodes, tree.ordered_prims, verts, rays, nthreads=8)
+    assert hits_t.cpu().numpy().view(HIT_DTYPE).reshape(-1).tobytes() == exp.tobytes()
+    agg.close()
+
+
+@pytest.mark.gpu
 def test_gpu_wavefront_bad_arguments():
     import ctypes
     verts, prims, tree, agg, rays, _ = _setup(51, 16)
