@@ -101,6 +101,10 @@ constexpr int kEnter = (int)0x80000002;   // INST = 2: the lane waits to enter a
 #ifndef NNBVH_FAT
 #define NNBVH_FAT 0
 #endif
+// 1: a far child pushed and popped within the same step is taken from registers (experiment)
+#ifndef NNBVH_FWD_TOP
+#define NNBVH_FWD_TOP 0
+#endif
 // SOA = 1 (lean instances of modes 0, 2, 3 only): a batch without nnbvh_ray records (rays == nullptr) is read as the
 // SOA<Ray> slices of a wavefront queue — no gather pass.  Its own instances: the mere presence of the second fetch
 // path in the refill trip cost the one-launch step 1.3 % (9.31 -> 9.44 ms).
@@ -441,19 +445,32 @@ void trace_kernel(TraceParams p) {
         // it), and the reference tests the far child against that later value.  MODE 1 pushes every
         // far child (exact counts up to the first hit).
         const bool doPush = (MODE == 1) || (farT < __builtin_inff());
-        if (doPush && sp - base == W - 1) {
-            uint2 e;
-            e.x = __float_as_uint(stk[base & (W - 1)][0][lane]);
-            e.y = __float_as_uint(stk[base & (W - 1)][1][lane]);
-            p.spill[(long)base * spillStride + gtid] = e;
-            ++base;
+#if NNBVH_FWD_TOP
+        // near child missed, far child hit: the entry about to be pushed is the one pop_next would hand straight back —
+        // take it from the registers (no LDS write + read, no spill of the oldest entry on its behalf)
+        const bool takeFar = doPush && !(nearT < tMax) && (farT < tMax);
+        if (!takeFar) {
+#else
+        constexpr bool takeFar = false;
+        {
+#endif
+            if (doPush && sp - base == W - 1) {
+                uint2 e;
+                e.x = __float_as_uint(stk[base & (W - 1)][0][lane]);
+                e.y = __float_as_uint(stk[base & (W - 1)][1][lane]);
+                p.spill[(long)base * spillStride + gtid] = e;
+                ++base;
+            }
+            stk[sp & (W - 1)][0][lane] = __int_as_float(farRef);
+            stk[sp & (W - 1)][1][lane] = farT;
+            sp += doPush ? 1 : 0;
         }
-        stk[sp & (W - 1)][0][lane] = __int_as_float(farRef);
-        stk[sp & (W - 1)][1][lane] = farT;
-        sp += doPush ? 1 : 0;
         if (MODE == 0 || MODE == 3) visited += doPush ? 0 : 1;
         if (nearT < tMax) cur = nearRef;
-        else cur = pop_next();
+        else if (takeFar) {
+            if (MODE != 2) visited += 1;  // as pop_entry counts the popped entry
+            cur = farRef;
+        } else cur = pop_next();
     };
     auto interior_step = [&]() {
 #ifdef NNBVH_STATS
