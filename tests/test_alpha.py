@@ -341,6 +341,13 @@ def test_device_alpha_patches_equal_oracle():
     assert dev.Intersect(rays).tobytes() == got.tobytes()
     assert np.array_equal(dev.IntersectP(rays), occ)
     dev.close()
+    # ... and through the device HLBVH builder (another primitive order: the gather of the per-primitive alpha)
+    th = build_tree(prims, verts, 4, "hlbvh")
+    dev = BVHAggregate.build_on_device(prims, verts, 4, "hlbvh", normals=normals, prim_alpha=alpha, uvs=uvs)
+    sub = rays[:30000]
+    eh, _ = _oracle_alpha_patch(th, verts, normals, alpha[th.ordered_prims["id"]], sub)
+    assert dev.Intersect(sub).tobytes() == eh.tobytes()
+    dev.close()
     n_ord = len(rays) - len(weird)
     assert got[:n_ord].tobytes() == exp[:n_ord].tobytes()
     # the degenerate rays: a NaN ray can be accepted with NaN t / barycentrics (shapes.cpp:239-266); x86 and gfx950
