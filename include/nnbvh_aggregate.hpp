@@ -231,6 +231,20 @@ class HipBVHAggregate {
             fatal("IntersectShadowQueue");
     }
 
+    // == IntersectShadow of one depth + IntersectClosest of the next (the render loop issues them back to back,
+    //    wavefront/integrator.cpp) in ONE launch of the traversal kernel; same results as the two calls
+    void IntersectClosestAndShadowQueues(int maxRays, const nnbvh_ray_soa &rayQueue, const int32_t *dSize,
+                                         const uint8_t *dPrimClass, int64_t nPrimClass, void *dHits,
+                                         const nnbvh_closest_queues &out, int maxShadowRays,
+                                         const nnbvh_ray_soa &shadowQueue, const int32_t *dShadowSize, const float *dLd,
+                                         const float *dRu, const float *dRl, const int32_t *dPixelIndex, float *dL,
+                                         int64_t nPixels, void *stream, uint8_t *dOccluded = nullptr) const {
+        if (nnbvh_wavefront_intersect_closest_and_shadow(scene_, maxRays, &rayQueue, dSize, dPrimClass, nPrimClass, dHits,
+                                                         &out, maxShadowRays, &shadowQueue, dShadowSize, dLd, dRu, dRl,
+                                                         dPixelIndex, dL, nPixels, dOccluded, stream) != NNBVH_OK)
+            fatal("IntersectClosestAndShadowQueues");
+    }
+
     // == one wavefront iteration's independent queues as ONE launch (include/nnbvh.h)
     void TraceBatchesDevice(const nnbvh_batch *batches, int nBatches, void *stream) const {
         if (nnbvh_trace_batches_device(scene_, batches, nBatches, stream) != NNBVH_OK)
